@@ -1,0 +1,427 @@
+#!/opt/conda/bin/python3.9
+"""Generate tests/golden/*.json by running the REFERENCE's own functions.
+
+Build-container only (needs /root/reference).  Run with the interpreter that has a real
+h5py so the reference imports unmodified:
+
+    /opt/conda/bin/python3.9 oracle/make_golden.py
+
+What is called from the reference (zellerlab/stag 0.8.2):
+  stag.align.convert_alignment          (align.py:37-58)     -> encode.json
+  stag.align.protein2gene_alignment     (align.py:63-94)     -> backtranslate.json
+  stag.classify.classify_seq            (classify.py:94-124) -> classify_seq.json
+  stag.classify.run_logistic_prediction (classify.py:22-27)  -> sklearn_parity.json
+  stag.classify.classify                (classify.py:131-207, with load_db replaced by an
+                                         in-memory DB; output formatting is the reference's)
+                                                             -> tsv.json
+  stag.classify_genome.concat_alignments (classify_genome.py:364-388) -> concat.json
+  stag.databases.save_to_file           (databases.py:111-147) -> tiny.stagDB (+ tiny_db.json)
+
+Only inputs and the reference's outputs are stored; no reference source enters the repo.
+Floats are stored through repr(), which round-trips float64 exactly.
+"""
+import contextlib
+import io
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+sys.path.insert(0, "/root/reference")
+import stag.align as ref_align            # noqa: E402
+import stag.classify as ref_classify      # noqa: E402
+import stag.classify_genome as ref_genome  # noqa: E402
+import stag.databases as ref_db           # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def dump(name, obj):
+    with open(os.path.join(OUT, name), "w") as fh:
+        json.dump(obj, fh, indent=0, separators=(",", ":"))
+    print("wrote", name)
+
+
+def bits_str(a):
+    return "".join("1" if b else "0" for b in a)
+
+
+# ---------------------------------------------------------------- encode (a1)
+def gen_encode():
+    rng = np.random.default_rng(1)
+    cases = ["ACGTU", "acgtu", "-", ".", "N", "ACGTUacgtu-.N*RYKMSWBDHVn", "-----", "A", "a",
+             "", "ac.gt", "AC-GT..NNacgtACGU--", "*", "ACGT" * 40 + "acg" + "-" * 7,
+             "U" * 64, "-" * 63 + "A", "ac" * 5 + "G", "AcCgGtTuU-", "XZ@[`{|}~ 09azAZ"]
+    alphabet = list("ACGTU-.N") + list("acgtn") + list("RYKM*")
+    p = np.array([6, 6, 6, 6, 2, 8, 1, 1] + [0.4] * 5 + [0.2] * 5, dtype=float)
+    p /= p.sum()
+    for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 129, 300, 1031):
+        cases.append("".join(rng.choice(alphabet, size=n, p=p)))
+    out = []
+    for s in cases:
+        try:
+            with contextlib.redirect_stderr(io.StringIO()):
+                bits, pct = ref_align.convert_alignment(s, 1, as_numpy=True)
+            out.append({"a2m": s, "bits": bits_str(bits), "pct": repr(float(pct))})
+        except ZeroDivisionError:
+            out.append({"a2m": s, "error": "ZeroDivisionError"})
+    dump("encode.json", out)
+
+
+# ---------------------------------------------------------------- back-translation (a2)
+def gen_backtranslate():
+    cases = [
+        ("MKV", "ATGAAAGTT"),
+        ("MKV", "ATGAAAGTTTAA"),           # stop codon
+        ("MKV", "ATGAAAGT"),               # wrong length -> None
+        ("M-KV", "ATGAAAGTT"),
+        ("-M-K-V-", "ATGAAAGTTTGA"),
+        ("MkV", "ATGAAAGTT"),              # lowercase residue consumed, not emitted
+        ("mkv", "ATGAAAGTT"),
+        ("--", ""),
+        ("M.KV", "ATGAAAGTTCCC"),          # '.' counts as a residue for the length check, emits nothing
+        ("MK*", "ATGAAATAA"),              # '*' is neither upper nor lower
+        ("MKV", "atgaaagtt"),              # gene kept "as is" (lowercase nt are dropped later by a1)
+        ("M-kKv-V", "ATGCCCAAAGGGGTTTAG"),
+        ("", ""),
+    ]
+    out = []
+    for prot, gene in cases:
+        for check in (True, False):
+            with contextlib.redirect_stderr(io.StringIO()):
+                r = ref_align.protein2gene_alignment("id1", prot, gene, check_length=check)
+            out.append({"protein": prot, "gene": gene, "check_length": check, "result": r})
+    dump("backtranslate.json", out)
+
+
+# ---------------------------------------------------------------- synthetic DBs for a5-a11
+def rand_onehot(rng, ncol, kind):
+    x = np.zeros(5 * ncol, dtype=bool)
+    if kind == "onehot":
+        sym = rng.integers(0, 5, size=ncol)
+        x[5 * np.arange(ncol) + sym] = True
+    elif kind == "zerofill":       # some columns carry no bit (classify_genome.py:375)
+        sym = rng.integers(0, 5, size=ncol)
+        keep = rng.random(ncol) < 0.6
+        x[(5 * np.arange(ncol) + sym)[keep]] = True
+    elif kind == "anybits":        # arbitrary -s input
+        x = rng.random(5 * ncol) < 0.3
+    elif kind == "allzero":
+        pass
+    return x
+
+
+def make_tree(rng, fanouts, ncol, density=0.3, scale=2.0, single_kind="string"):
+    """fanouts: list per level of candidate fan-outs to draw from."""
+    L = 5 * ncol
+    taxonomy = {"tree_root": []}
+    classifiers = {}
+    frontier = ["tree_root"]
+    for lvl, choices in enumerate(fanouts):
+        nxt = []
+        for parent in frontier:
+            k = int(rng.choice(choices))
+            kids = ["L%d_%s_%d" % (lvl, parent[-6:].replace("tree_r", "r"), j) for j in range(k)]
+            kids = ["%s|%d" % (kid, len(taxonomy) + j) for j, kid in enumerate(kids)]
+            taxonomy[parent] = kids
+            for kid in kids:
+                taxonomy[kid] = []
+                w = rng.normal(0, scale, size=1 + L) * (rng.random(1 + L) < density)
+                w[0] = rng.normal(-1, 1)
+                if k == 1 and single_kind == "string":
+                    classifiers[kid] = "no_negative_examples"
+                else:
+                    classifiers[kid] = w
+            nxt.extend(kids)
+        frontier = nxt
+    return taxonomy, classifiers
+
+
+def db_to_json(taxonomy, tax_function, classifiers):
+    return {
+        "taxonomy": taxonomy,
+        "tax_function": {k: [repr(float(v)) for v in row] for k, row in tax_function.items()},
+        "classifiers": {k: (v if isinstance(v, str) else [repr(float(x)) for x in v])
+                        for k, v in classifiers.items()},
+    }
+
+
+def run_case(name, taxonomy, tax_function, classifiers, seqs, note=""):
+    rows = []
+    for i, x in enumerate(seqs):
+        try:
+            with np.errstate(over="ignore"):
+                r = ref_classify.classify_seq("seq%d" % i, x, taxonomy, tax_function, classifiers, 1, 1)
+            rows.append({"row": r})
+        except Exception as e:  # the exception class is part of the contract
+            rows.append({"error": [c.__name__ for c in type(e).__mro__]})
+    case = db_to_json(taxonomy, tax_function, classifiers)
+    case.update({"name": name, "note": note, "L": int(len(seqs[0])),
+                 "seqs": [bits_str(x) for x in seqs], "expected": rows})
+    return case
+
+
+def gen_classify_seq():
+    cases = []
+    # A: generic random tree, depth 3, fan-outs 1..5, one-hot inputs
+    rng = np.random.default_rng(11)
+    ncol = 24
+    tax, cls = make_tree(rng, [[3, 4], [1, 2, 3, 5], [1, 2, 4]], ncol)
+    tf = {str(l): rng.normal(0, 1, size=4) for l in (-1, 0, 1, 2)}
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(40)]
+    cases.append(run_case("A_random_depth3", tax, tf, cls, seqs))
+
+    # B: zero-filled / arbitrary / all-zero inputs on another tree; leaves at different depths
+    rng = np.random.default_rng(12)
+    ncol = 31
+    tax, cls = make_tree(rng, [[2, 3], [0, 2, 3], [0, 1, 2], [2]], ncol, density=0.15)
+    D = 4
+    tf = {str(l): rng.normal(0, 1.5, size=1 + D) for l in (-1, 0, 1, 2, 3)}
+    seqs = ([rand_onehot(rng, ncol, "zerofill") for _ in range(15)] +
+            [rand_onehot(rng, ncol, "anybits") for _ in range(15)] +
+            [rand_onehot(rng, ncol, "allzero")])
+    # paths shorter than D make coeff*perc fail to broadcast -> ValueError (classify.py:25)
+    cases.append(run_case("B_ragged_depth_inputs", tax, tf, cls, seqs,
+                          "paths of length != n_tf raise ValueError unless one length is 1"))
+
+    # C: exact ties (duplicated rows), fp64 saturation to 1.0, single-child root
+    rng = np.random.default_rng(13)
+    ncol = 12
+    L = 5 * ncol
+    taxonomy = {"tree_root": ["only"], "only": ["a", "b", "c", "d"],
+                "a": ["a1", "a2"], "b": ["b1", "b2", "b3"], "c": ["c1"], "d": [],
+                "a1": [], "a2": [], "b1": [], "b2": [], "b3": [], "c1": []}
+    w_dup = rng.normal(0, 1, size=1 + L)
+    w_big = np.concatenate([[50.0], np.abs(rng.normal(0, 1, size=L))])      # sigmoid == 1.0
+    w_big2 = np.concatenate([[80.0], np.abs(rng.normal(0, 1, size=L))])     # also exactly 1.0
+    classifiers = {
+        "only": "no_negative_examples",
+        "a": w_dup, "b": w_dup.copy(), "c": rng.normal(0, 1, size=1 + L), "d": rng.normal(0, 1, size=1 + L),
+        "a1": w_big, "a2": w_big2,
+        "b1": rng.normal(0, 1, size=1 + L), "b2": w_dup.copy(), "b3": w_dup.copy(),
+        "c1": "no_negative_examples",
+    }
+    classifiers["c"][0] += 3.0
+    tf = {str(l): rng.normal(0, 1, size=4) for l in (-1, 0, 1, 2)}
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(30)]
+    cases.append(run_case("C_ties_saturation_single_root", taxonomy, tf, classifiers, seqs,
+                          "a==b rows identical: first stored child wins; a1/a2 both saturate to 1.0"))
+
+    # D: 12 levels -> keys '10','11' sort before '2' (classify.py:62); chain of single children inside
+    rng = np.random.default_rng(14)
+    ncol = 10
+    tax, cls = make_tree(rng, [[2], [2], [1], [2], [1], [1], [2], [2], [1], [2], [2], [2]], ncol,
+                         density=0.4, scale=1.0)
+    D = 12
+    tf = {str(l): rng.normal(0, 1, size=1 + D) for l in range(-1, D)}
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(12)]
+    cases.append(run_case("D_twelve_levels_string_sort", tax, tf, cls, seqs))
+
+    # E: huge negative logits (exp overflow -> prob 0.0), rank-cut never above 0 -> selected -1 (int)
+    rng = np.random.default_rng(15)
+    ncol = 8
+    L = 5 * ncol
+    taxonomy = {"tree_root": ["x", "y"], "x": ["x1", "x2"], "y": ["y1", "y2"],
+                "x1": [], "x2": [], "y1": [], "y2": []}
+    classifiers = {k: np.concatenate([[-800.0], -np.abs(rng.normal(0, 1, size=L))])
+                   for k in ("x", "y", "x1", "x2", "y1", "y2")}
+    classifiers["y1"] = rng.normal(0, 1, size=1 + L)
+    tf = {"-1": np.array([-900.0, 0.0, 0.0]), "0": np.array([-900.0, 1.0, 1.0]),
+          "1": np.array([-1000.0, 1.0, 1.0])}
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(6)]
+    cases.append(run_case("E_overflow_selected_minus1", taxonomy, tf, classifiers, seqs,
+                          "all probabilities 0.0: first child wins (0.0 > -1); selected_level stays int -1"))
+
+    # F: error contracts: missing classifier (KeyError), string classifier evaluated, empty root
+    rng = np.random.default_rng(16)
+    ncol = 6
+    L = 5 * ncol
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(3)]
+    tf = {"-1": rng.normal(size=3), "0": rng.normal(size=3), "1": rng.normal(size=3)}
+    taxonomy = {"tree_root": ["p", "q"], "p": ["p1", "p2"], "q": [], "p1": [], "p2": []}
+    good = {k: rng.normal(0, 1, size=1 + L) for k in ("p", "q", "p1", "p2")}
+    good["p"][0] += 30
+    missing = dict(good)
+    del missing["p2"]
+    cases.append(run_case("F1_missing_classifier", taxonomy, tf, missing, seqs))
+    strrow = dict(good)
+    strrow["p1"] = "no_negative_examples"
+    cases.append(run_case("F2_string_classifier_evaluated", taxonomy, tf, strrow, seqs))
+    cases.append(run_case("F3_root_without_children", {"tree_root": []}, tf, {}, seqs))
+    cases.append(run_case("F4_root_missing", {"other": ["z"]}, tf, {}, seqs))
+    # child that is not itself a taxonomy key: walk stops there
+    tax5 = {"tree_root": ["p", "q"], "p": ["p1", "p2"], "q": []}
+    cases.append(run_case("F5_child_not_a_key", tax5, {k: v[:3] for k, v in tf.items()}, good, seqs))
+    # rank-cut with a single coefficient (1+1): broadcasts against any path length
+    tf1 = {"0": np.array([0.3, -1.2]), "-1": np.array([-0.1, 0.7])}
+    cases.append(run_case("F6_rankcut_len1_broadcast", taxonomy, tf1, good, seqs))
+    dump("classify_seq.json", cases)
+
+
+# ---------------------------------------------------------------- sklearn parity (north_star 1e-9)
+def gen_sklearn():
+    from sklearn.linear_model import LogisticRegression
+    rng = np.random.default_rng(21)
+    ncol = 40
+    L = 5 * ncol
+    n = 120
+    proto = rng.integers(0, 5, size=(2, ncol))
+    X = np.zeros((n, L), dtype=bool)
+    y = []
+    for i in range(n):
+        c = i % 2
+        sym = proto[c].copy()
+        mut = rng.random(ncol) < 0.15
+        sym[mut] = rng.integers(0, 5, size=mut.sum())
+        X[i, 5 * np.arange(ncol) + sym] = True
+        y.append("yes" if c else "no")
+    # create_db.py:132 (penalty l1, liblinear), classes sorted -> column 1 is "yes" (create_db.py:124)
+    clf = LogisticRegression(random_state=0, penalty="l1", solver="liblinear")
+    clf.fit(X, np.array(y))
+    row = np.append(clf.intercept_, clf.coef_)       # databases.py:140
+    proba = clf.predict_proba(X)[:, 1]
+    ref = [float(ref_classify.run_logistic_prediction(X[i], row)) for i in range(n)]
+    dump("sklearn_parity.json", {
+        "L": L, "row": [repr(float(v)) for v in row],
+        "X": [bits_str(x) for x in X],
+        "predict_proba": [repr(float(v)) for v in proba],
+        "run_logistic_prediction": [repr(v) for v in ref],
+        "sklearn_version": __import__("sklearn").__version__,
+    })
+
+
+# ---------------------------------------------------------------- classify() TSV text (a12)
+def gen_tsv():
+    rng = np.random.default_rng(31)
+    ncol = 16
+    tax, cls = make_tree(rng, [[2, 3], [1, 2, 3], [2]], ncol)
+    tf = {str(l): rng.normal(0, 1, size=4) for l in (-1, 0, 1, 2)}
+    seqs = [rand_onehot(rng, ncol, "onehot") for _ in range(8)]
+    ali_lines = ["read_%d\t%s" % (i, "\t".join("1" if b else "0" for b in x)) for i, x in enumerate(seqs)]
+    out = {"db": db_to_json(tax, tf, cls), "L": 5 * ncol, "ali_lines": ali_lines, "runs": {}}
+
+    def fake_load_db(path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):
+        hmm = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        hmm.write("NA")
+        hmm.close()
+        return hmm.name, False, tax, tf, cls, "0.8.2"
+
+    real = ref_classify.load_db
+    ref_classify.load_db = fake_load_db
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            ali = os.path.join(tmp, "ali.tsv")
+            with open(ali, "w") as fh:
+                fh.write("\n".join(ali_lines) + "\n")
+            for tag, kw in (("short", {}), ("long", {"long_out": True}),
+                            ("internal", {"internal_call": True, "long_out": True})):
+                res = os.path.join(tmp, "out_" + tag)
+                ret = ref_classify.classify("db", aligned_sequences=ali, output=res, verbose=1, **kw)
+                text = open(res).read() if os.path.exists(res) else None
+                out["runs"][tag] = {"kwargs": kw, "return_len": ret[0], "return_rows": ret[1], "file": text}
+            class _Keep(io.StringIO):     # classify() closes sys.stdout (`with outfile:`)
+                def close(self):
+                    self.kept = self.getvalue()
+                    super().close()
+            buf = _Keep()
+            with contextlib.redirect_stdout(buf):
+                ref_classify.classify("db", aligned_sequences=ali, verbose=1)
+            out["runs"]["stdout_short"] = {"kwargs": {}, "file": buf.kept}
+    finally:
+        ref_classify.load_db = real
+    # the -S line format (classify.py:160-162)
+    x = seqs[0]
+    buf = io.StringIO()
+    print("read_0", *np.char.mod('%.0f', x), sep="\t", file=buf)
+    out["save_ali_line"] = buf.getvalue()
+    dump("tsv.json", out)
+
+
+# ---------------------------------------------------------------- concat_alignments (a15)
+def gen_concat():
+    rng = np.random.default_rng(41)
+    gene_order = ["COG0012", "COG0016", "COG0018"]
+    ali_lengths = {"COG0012": "10", "COG0016": "15", "COG0018": "5"}
+    files = {
+        "COG0012": ["dir/genomeA.fna_12##COG0012", "dir/genomeB.fna_7##COG0012", "plain.3##COG0012"],
+        "COG0016": ["dir/genomeA.fna_40##COG0016", "solo##COG0016"],
+        # COG0018 file does not exist
+    }
+    with tempfile.TemporaryDirectory() as tmp:
+        stored = {}
+        for mg, ids in files.items():
+            lines = []
+            for gid in ids:
+                bits = (rng.random(int(ali_lengths[mg])) < 0.4).astype(int)
+                lines.append(gid + "\t" + "\t".join(map(str, bits)))
+            stored[mg] = lines
+            with open(os.path.join(tmp, mg), "w") as fh:
+                fh.write("\n".join(lines) + "\n")
+        with contextlib.redirect_stdout(io.StringIO()):
+            path = ref_genome.concat_alignments(None, tmp, gene_order, ali_lengths)
+        text = open(path).read()
+        os.remove(path)
+    dump("concat.json", {"gene_order": gene_order, "ali_lengths": ali_lengths,
+                         "ali_files": stored, "concatenated": text})
+
+
+# ---------------------------------------------------------------- stagDB written by the reference writer
+class _Model:   # what save_to_file reads from an sklearn model: intercept_ and coef_
+    def __init__(self, row):
+        self.intercept_ = np.array([row[0]])
+        self.coef_ = np.array([row[1:]])
+
+
+def gen_stagdb():
+    from stag.taxonomy3 import Taxonomy
+    rng = np.random.default_rng(51)
+    ncol = 29                                    # LENG 29 of stag/test/gene.hmm
+    L = 5 * ncol
+    with tempfile.TemporaryDirectory() as tmp:
+        taxfile = os.path.join(tmp, "tax.tsv")
+        lines = ["g1\tBacteria;Firmicutes;Bacilli", "g2\tBacteria;Firmicutes;Clostridia",
+                 "g3\tBacteria;Bacteroidetes;Bacteroidia", "g4\tBacteria;Proteobacteria;Alpha",
+                 "g5\tBacteria;Proteobacteria;Gamma", "g6\tBacteria;Proteobacteria;Beta/Delta"]
+        with open(taxfile, "w") as fh:
+            fh.write("\n".join(lines) + "\n")
+        full = Taxonomy(taxfile)
+        full.load_from_file()
+        nodes = [n for n, _ in full.get_all_nodes(get_root=False)]
+        classifiers = {}
+        for n in nodes:
+            sibs = full.find_node(n) if hasattr(full, "find_node") else None
+            row = rng.normal(0, 1.5, size=1 + L) * (rng.random(1 + L) < 0.2)
+            row[0] = rng.normal()
+            classifiers[n] = _Model(row)
+        classifiers["Bacteroidia"] = "no_negative_examples"   # single child (databases.py:145)
+        classifiers["Bacteria"] = "no_negative_examples"
+        tf = {l: _Model(rng.normal(0, 1, size=4)) for l in (-1, 0, 1, 2)}
+        path = os.path.join(OUT, "tiny.stagDB")
+        hmm = "/root/reference/stag/test/gene.hmm"
+        ref_db.save_to_file(classifiers, full, tf, False, path, hmm_file_path=hmm, protein_fasta_input=None)
+        meta = {
+            "taxonomy": {n: list(full[n].children.keys()) for n, _ in full.get_all_nodes(get_root=True)},
+            "tax_function": {str(k): [repr(float(v)) for v in np.append(m.intercept_, m.coef_)]
+                             for k, m in tf.items()},
+            "classifiers": {k: (m if isinstance(m, str) else
+                                [repr(float(v)) for v in np.append(m.intercept_, m.coef_)])
+                            for k, m in classifiers.items()},
+            "use_cmalign": False, "align_protein": False, "tool_version": ref_db.tool_version,
+            "hmm_sha1": __import__("hashlib").sha1(open(hmm, "rb").read()).hexdigest(),
+            "hmm_len": os.path.getsize(hmm),
+        }
+        dump("tiny_db.json", meta)
+        print("wrote tiny.stagDB", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    gen_encode()
+    gen_backtranslate()
+    gen_classify_seq()
+    gen_sklearn()
+    gen_tsv()
+    gen_concat()
+    gen_stagdb()
