@@ -1,0 +1,148 @@
+/*
+ * stag_hip.h -- C ABI of libstag_hip.so, the MI355X (gfx950) implementation of STAG's
+ * post-alignment classification path.
+ *
+ * The reference (zellerlab/stag 0.8.2, pure Python) has no FFI layer; these entry points are
+ * what a binding for this path replaces, function by function (paths relative to the
+ * reference root):
+ *
+ *   stag_encode_a2m*      <- stag/align.py:28-58   convert_alignment  (+ :160 min_perc_state filter)
+ *   stag_backtranslate    <- stag/align.py:63-94   protein2gene_alignment
+ *   stag_classify_bits*   <- stag/classify.py:22-124  run_logistic_prediction, find_best_score,
+ *                            predict_iter, find_correct_level, find_n_aligned_characters, classify_seq
+ *   stag_classify_a2m*    <- the loop body of stag/classify.py:155-158 fed by stag/align.py:149-164
+ *   stag_db_create        <- the in-memory result of stag/databases.py:36-108 load_db, packed
+ *
+ * Conventions: plain C types only; every function returns STAG_OK (0) or a negative
+ * STAG_E_* code and stag_last_error() then describes it (thread-local); the caller owns
+ * all buffers; the library keeps no pointer after a call returns except inside the opaque
+ * stag_db_t.  Per-sequence failures (the reference's Python exceptions) are reported in
+ * status[] as STAG_SEQ_* and never abort the batch.  Functions ending in _dev take DEVICE
+ * pointers and a hipStream_t (passed as void*; NULL = the null stream) and return without
+ * synchronising; the others take HOST pointers and are synchronous.
+ *
+ * One stag_db_t lives on one GPU.  Calls on the same handle must not overlap (they share
+ * the handle's workspace); different handles are independent.
+ */
+#ifndef STAG_HIP_H
+#define STAG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STAG_OK 0
+#define STAG_E_INVALID (-1)   /* bad argument / inconsistent tables */
+#define STAG_E_HIP (-2)       /* a HIP runtime call failed */
+#define STAG_E_NOMEM (-3)
+#define STAG_E_NOGPU (-4)     /* no usable gfx950 device */
+
+/* Per-sequence status.  1..5 are the exceptions the reference raises for that sequence. */
+#define STAG_SEQ_OK 0
+#define STAG_SEQ_MISSING_CLASSIFIER 1 /* KeyError:  classifiers[sibling]            classify.py:40 */
+#define STAG_SEQ_STRING_CLASSIFIER 2  /* TypeError: "no_negative_examples" evaluated classify.py:24-25 */
+#define STAG_SEQ_RANKCUT_SHAPE 3      /* ValueError: coeff * perc does not broadcast classify.py:25 */
+#define STAG_SEQ_EMPTY_PATH 4         /* IndexError: perc[0] on an empty path        classify.py:106 */
+#define STAG_SEQ_ZERO_COLUMNS 5       /* ZeroDivisionError: n_char == 0              align.py:58 */
+#define STAG_SEQ_FILTERED 6           /* below min_perc_state: not yielded           align.py:160 */
+#define STAG_SEQ_LENGTH_MISMATCH 7    /* ValueError: 5*n_char != L (coeff * seq)     classify.py:25 */
+
+/*
+ * Host-side description of one single-gene database (what load_db returns), already
+ * numbered: tree positions in breadth-first order, root ("tree_root") = 0, so that the
+ * children of node i are the consecutive ids child_first[i] .. child_first[i+1]-1 in the
+ * order the database stores them (classify.py:39 iterates them in that order).
+ */
+typedef struct {
+    int32_t n_nodes;
+    int32_t n_features;        /* L = 5 * alignment columns */
+    const int32_t *child_first; /* [n_nodes+1]; child_first[0] == 1, child_first[n_nodes] == n_nodes */
+    const uint8_t *row_kind;   /* [n_nodes] 0 = no classifier, 1 = coefficients, 2 = "no_negative_examples" */
+    const double *intercept;   /* [n_nodes] coeff_raw[0] (classify.py:24) */
+    const int64_t *row_off;    /* [n_nodes+1] CSR over the non-zero coefficients of each row */
+    const int32_t *row_feat;   /* feature index 0..L-1, ascending inside a row */
+    const double *row_w;       /* coefficient of that feature */
+    int32_t n_keys;            /* rank-cut keys, in sorted(str) order (classify.py:62) */
+    int32_t n_tf;              /* coefficients per rank-cut row (excluding the intercept) */
+    const double *tf;          /* [n_keys][1+n_tf] */
+} stag_tables_t;
+
+/* Per-sequence outputs.  Any pointer may be NULL (that output is skipped), except status. */
+typedef struct {
+    int32_t *path_node;     /* [n][max_depth] node ids along the greedy walk, -1 beyond path_len */
+    double *path_prob;      /* [n][max_depth] after the placeholder fix-up of classify.py:106-110 */
+    int32_t *path_len;      /* [n] */
+    int32_t *n_lead_single; /* [n] leading levels decided by "exactly one child" (they print as int 1) */
+    double *level_prob;     /* [n][n_keys] find_correct_level probabilities, sorted-key order */
+    int32_t *selected;      /* [n] index into the sorted keys, -1 = nothing selected */
+    int32_t *n_aligned;     /* [n] find_n_aligned_characters */
+    int32_t *status;        /* [n] STAG_SEQ_* */
+} stag_results_t;
+
+typedef struct stag_db stag_db_t;
+
+const char *stag_last_error(void);
+int stag_device_count(int32_t *count);
+
+/* Packs the tables into device memory on GPU `device`. */
+int stag_db_create(const stag_tables_t *tables, int32_t device, stag_db_t **out);
+void stag_db_destroy(stag_db_t *db);
+/* max_depth: longest root-to-leaf path; words_per_row: uint32 words of one packed one-hot row. */
+int stag_db_info(const stag_db_t *db, int32_t *max_depth, int32_t *words_per_row, int32_t *n_keys,
+                 int64_t *table_bytes);
+/* Grows the handle's device workspace for batches of up to n sequences / text_bytes bytes. */
+int stag_db_reserve(stag_db_t *db, int64_t n, int64_t text_bytes);
+
+/* uint32 words per packed row for L features (multiple of 4, so rows are 16-byte aligned). */
+int32_t stag_words_per_row(int32_t n_features);
+
+/*
+ * align.py:37-58 + :160.  text holds n aligned (A2M) strings back to back; string i is
+ * text[offs[i] .. offs[i+1]).  '\n' and '\r' inside a string are skipped (A2M records may be
+ * line-wrapped; helpers.py:112 strips them).  Output row i (words_per_row words) has bit f set
+ * iff one-hot feature f of string i is True: word f>>5, bit f&31.  status: OK, ZERO_COLUMNS,
+ * FILTERED (pct < min_perc_state) or LENGTH_MISMATCH (5*n_char != n_features).
+ */
+int stag_encode_a2m(int32_t device, int32_t n_features, const char *text, const int64_t *offs, int64_t n,
+                    double min_perc_state, uint32_t *bits, int32_t *n_char, int32_t *n_aligned,
+                    int32_t *status);
+int stag_encode_a2m_dev(int32_t n_features, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
+                        int64_t n, double min_perc_state, uint32_t *d_bits, int32_t *d_n_char,
+                        int32_t *d_n_aligned, int32_t *d_status, void *stream);
+
+/* classify.py:94-124 for n packed rows.  status_in (may be NULL) carries encode's status:
+ * sequences that are not STAG_SEQ_OK are skipped and keep their status. */
+int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int32_t *status_in,
+                       const stag_results_t *out);
+int stag_classify_bits_dev(stag_db_t *db, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in,
+                           const stag_results_t *d_out, void *stream);
+
+/* Encode + classify without the rows leaving the GPU.  bits_out (may be NULL) receives the
+ * packed rows (for -S, classify.py:160-162). */
+int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n,
+                      double min_perc_state, const stag_results_t *out, uint32_t *bits_out,
+                      int32_t *n_char_out);
+int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
+                          int64_t n, double min_perc_state, const stag_results_t *d_out, void *stream);
+
+/* align.py:63-94 on the host (string work; the GPU version is a later row of SURVEY.md 8f).
+ * out must hold 3*prot_len bytes.  *out_len = -1 reproduces the reference's `return None`. */
+int stag_backtranslate(const char *prot, int64_t prot_len, const char *gene, int64_t gene_len,
+                       int32_t check_length, char *out, int64_t *out_len);
+
+/*
+ * Per-kernel device timing for bench.py: when enabled every launch on this handle is
+ * bracketed by HIP events on the launch stream.  stag_profile_read synchronises, sums the
+ * elapsed times per kernel class and clears the record.  Classes: 0 encode, 1 walk_level,
+ * 2 group (assign/scan/scatter), 3 rankcut, 4 other.
+ */
+#define STAG_PROF_CLASSES 5
+int stag_profile_enable(stag_db_t *db, int32_t on);
+int stag_profile_read(stag_db_t *db, double *ms_per_class, int64_t *launches_per_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STAG_HIP_H */

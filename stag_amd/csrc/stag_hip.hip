@@ -1,0 +1,603 @@
+// libstag_hip.so: C ABI (include/stag_hip.h) + host side of the MI355X classify path.
+// gfx950 only; no CPU fallback: every entry point fails with STAG_E_NOGPU/STAG_E_HIP when
+// the GPU is not usable.
+#include "stag_hip.h"
+#include "stag_kernels.hip.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace stagk;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(e_ == hipErrorOutOfMemory ? STAG_E_NOMEM : STAG_E_HIP, "%s: %s (%s:%d)", #expr, \
+                        hipGetErrorString(e_), __FILE__, __LINE__);                           \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;  // elements
+    int reserve(size_t n) {
+        if (n <= cap) return STAG_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
+        cap = n;
+        return STAG_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct ProfRec {
+    hipEvent_t a, b;
+    int cls;
+};
+
+}  // namespace
+
+struct stag_db {
+    int device = 0;
+    int n_nodes = 0, L = 0, W = 0, nchunks = 0, max_depth = 0, n_keys = 0, n_tf = 0;
+    std::vector<int> level_start;  // nodes of level d are [level_start[d], level_start[d+1])
+    int max_level_nodes = 1;
+    int64_t table_bytes = 0;
+    // tables
+    DevBuf<int32_t> child_first;
+    DevBuf<uint8_t> node_err;
+    DevBuf<double> intercept;
+    DevBuf<uint32_t> blk_off;
+    DevBuf<uint4> blocks;
+    DevBuf<double> tf;
+    // workspace (grown by reserve)
+    int64_t cap_n = 0;
+    DevBuf<int32_t> node, pos, order, count, node_off, task_off, n_tasks;
+    DevBuf<Task> tasks;
+    DevBuf<uint32_t> bits;
+    DevBuf<uint8_t> text;
+    DevBuf<int64_t> offs;
+    DevBuf<int32_t> enc_n_char, enc_status;
+    // results (used when the caller passes NULL or host pointers)
+    DevBuf<int32_t> r_path_node, r_path_len, r_lead, r_selected, r_n_aligned, r_status;
+    DevBuf<double> r_path_prob, r_level_prob;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> recs;
+
+    void free_all() {
+        child_first.release(); node_err.release(); intercept.release(); blk_off.release();
+        blocks.release(); tf.release(); node.release(); pos.release(); order.release();
+        count.release(); node_off.release(); task_off.release(); n_tasks.release(); tasks.release();
+        bits.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
+        r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
+        r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
+        for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        recs.clear();
+    }
+};
+
+namespace {
+
+struct Prof {  // brackets one launch with events when profiling is on
+    stag_db *db;
+    hipStream_t st;
+    ProfRec r{};
+    bool on;
+    Prof(stag_db *d, hipStream_t s, int cls) : db(d), st(s), on(d && d->prof) {
+        if (!on) return;
+        r.cls = cls;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(r.a, st);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(r.b, st);
+        db->recs.push_back(r);
+    }
+};
+
+int check_device(int device) {
+    int cnt = 0;
+    if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0)
+        return fail(STAG_E_NOGPU, "no HIP device visible (libstag_hip has no CPU path)");
+    if (device < 0 || device >= cnt) return fail(STAG_E_INVALID, "device %d out of range (0..%d)", device, cnt - 1);
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(STAG_E_NOGPU, "device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(device));
+    return STAG_OK;
+}
+
+int launch_check(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(STAG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+    return STAG_OK;
+}
+
+int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
+               double min_perc, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned, int32_t *d_status,
+               hipStream_t st) {
+    if (n == 0) return STAG_OK;
+    const int W = stag_words_per_row(L);
+    const size_t lds = (size_t)4 * W * sizeof(uint32_t);
+    if (lds > 160 * 1024) return fail(STAG_E_INVALID, "n_features %d too large for the encode kernel's LDS row buffers", L);
+    if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
+        return fail(STAG_E_INVALID, "d_text and d_bits must be 16-byte aligned");
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_encode_a2m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int64_t grid = (n + 3) / 4;
+    if (grid > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    {
+        Prof p(db_for_prof, st, 0);
+        hipLaunchKernelGGL(k_encode_a2m, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
+                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status);
+    }
+    return launch_check("k_encode_a2m");
+}
+
+// Resolved device pointers for one classify call.
+struct Out {
+    int32_t *path_node, *path_len, *lead, *selected, *n_aligned, *status;
+    double *path_prob, *level_prob;
+};
+
+int reserve_results(stag_db *db, int64_t n) {
+    const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
+    int rc;
+    if ((rc = db->r_path_node.reserve(n * D))) return rc;
+    if ((rc = db->r_path_prob.reserve(n * D))) return rc;
+    if ((rc = db->r_path_len.reserve(n))) return rc;
+    if ((rc = db->r_lead.reserve(n))) return rc;
+    if ((rc = db->r_level_prob.reserve(n * K))) return rc;
+    if ((rc = db->r_selected.reserve(n))) return rc;
+    if ((rc = db->r_n_aligned.reserve(n))) return rc;
+    if ((rc = db->r_status.reserve(n))) return rc;
+    return STAG_OK;
+}
+
+int reserve_walk(stag_db *db, int64_t n) {
+    int rc;
+    if ((rc = db->node.reserve(n))) return rc;
+    if ((rc = db->pos.reserve(n))) return rc;
+    if ((rc = db->order.reserve(n))) return rc;
+    if ((rc = db->tasks.reserve(n / TILE + db->max_level_nodes + 2))) return rc;
+    if ((rc = db->count.reserve(db->n_nodes))) return rc;
+    if ((rc = db->node_off.reserve(db->n_nodes))) return rc;
+    if ((rc = db->task_off.reserve(db->n_nodes))) return rc;
+    if ((rc = db->n_tasks.reserve(std::max(db->max_depth, 1)))) return rc;
+    if ((rc = reserve_results(db, n))) return rc;
+    db->cap_n = std::max(db->cap_n, n);
+    return STAG_OK;
+}
+
+Out resolve(stag_db *db, const stag_results_t *o) {
+    Out r;
+    r.path_node = o && o->path_node ? o->path_node : db->r_path_node.p;
+    r.path_prob = o && o->path_prob ? o->path_prob : db->r_path_prob.p;
+    r.path_len = o && o->path_len ? o->path_len : db->r_path_len.p;
+    r.lead = o && o->n_lead_single ? o->n_lead_single : db->r_lead.p;
+    r.level_prob = o && o->level_prob ? o->level_prob : db->r_level_prob.p;
+    r.selected = o && o->selected ? o->selected : db->r_selected.p;
+    r.n_aligned = o && o->n_aligned ? o->n_aligned : db->r_n_aligned.p;
+    r.status = o && o->status ? o->status : db->r_status.p;
+    return r;
+}
+
+// The level-synchronous walk + rank cut on device rows.  n_aligned must already be filled
+// (encode) unless count_aligned is set.
+int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in, const Out &o,
+             bool count_aligned, hipStream_t st) {
+    if (n == 0) return STAG_OK;
+    if (n > 0x7fffffff - 1024) return fail(STAG_E_INVALID, "batch of %lld sequences is too large; split it", (long long)n);
+    if ((uintptr_t)d_bits & 15) return fail(STAG_E_INVALID, "d_bits must be 16-byte aligned");
+    const int D = std::max(db->max_depth, 1);
+    const unsigned g256 = (unsigned)((n + 255) / 256);
+    if (count_aligned) {
+        Prof p(db, st, 4);
+        hipLaunchKernelGGL(k_count_aligned, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_bits, n, db->L, db->W,
+                           o.n_aligned);
+    }
+    {
+        Prof p(db, st, 2);
+        HIP_TRY(hipMemsetAsync(db->count.p, 0, sizeof(int32_t) * db->n_nodes, st));
+        hipLaunchKernelGGL(k_init_walk, dim3(g256), dim3(256), 0, st, n, D, d_status_in, o.status, db->node.p,
+                           o.path_node, o.path_len);
+    }
+    int rc;
+    if ((rc = launch_check("k_init_walk"))) return rc;
+    for (int d = 0; d < db->max_depth; ++d) {
+        const int lo = db->level_start[d], hi = db->level_start[d + 1];
+        {
+            Prof p(db, st, 2);
+            hipLaunchKernelGGL(k_assign, dim3(g256), dim3(256), 0, st, n, db->node.p, db->count.p, db->pos.p);
+            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->node_off.p,
+                               db->task_off.p, db->n_tasks.p + d);
+            hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, db->node.p, db->pos.p, db->count.p,
+                               db->node_off.p, db->task_off.p, db->order.p, db->tasks.p);
+        }
+        if ((rc = launch_check("grouping kernels"))) return rc;
+        WalkArgs a;
+        a.bits = d_bits; a.W = db->W; a.nchunks = db->nchunks; a.depth = d; a.D = D;
+        a.n_tasks = db->n_tasks.p + d; a.tasks = db->tasks.p; a.order = db->order.p;
+        a.child_first = db->child_first.p; a.node_err = db->node_err.p; a.intercept = db->intercept.p;
+        a.blk_off = db->blk_off.p; a.blocks = db->blocks.p; a.node = db->node.p;
+        a.path_node = o.path_node; a.path_prob = o.path_prob; a.path_len = o.path_len; a.status = o.status;
+        const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
+        {
+            Prof p(db, st, 1);
+            hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
+        }
+        if ((rc = launch_check("k_walk_level"))) return rc;
+    }
+    {
+        Prof p(db, st, 3);
+        hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), 0, st, n, D, db->n_keys, db->n_tf, db->tf.p, o.path_len,
+                           o.path_prob, o.lead, o.level_prob, o.selected, o.status);
+    }
+    return launch_check("k_rankcut");
+}
+
+template <typename T>
+int d2h(T *host, const T *dev, size_t count, hipStream_t st) {
+    if (!host || count == 0) return STAG_OK;
+    HIP_TRY(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, st));
+    return STAG_OK;
+}
+
+int copy_results_to_host(stag_db *db, const stag_results_t *out, int64_t n, hipStream_t st) {
+    const size_t D = std::max(db->max_depth, 1), K = db->n_keys;
+    int rc;
+    if ((rc = d2h(out->path_node, db->r_path_node.p, n * D, st))) return rc;
+    if ((rc = d2h(out->path_prob, db->r_path_prob.p, n * D, st))) return rc;
+    if ((rc = d2h(out->path_len, db->r_path_len.p, n, st))) return rc;
+    if ((rc = d2h(out->n_lead_single, db->r_lead.p, n, st))) return rc;
+    if ((rc = d2h(out->level_prob, db->r_level_prob.p, n * K, st))) return rc;
+    if ((rc = d2h(out->selected, db->r_selected.p, n, st))) return rc;
+    if ((rc = d2h(out->n_aligned, db->r_n_aligned.p, n, st))) return rc;
+    if ((rc = d2h(out->status, db->r_status.p, n, st))) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return STAG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *stag_last_error(void) { return g_err.c_str(); }
+
+int stag_device_count(int32_t *count) {
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) c = 0;
+    if (count) *count = c;
+    return STAG_OK;
+}
+
+int32_t stag_words_per_row(int32_t n_features) {
+    const int32_t w = (n_features + 31) / 32;
+    return std::max((w + 3) / 4 * 4, 4);
+}
+
+int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
+    if (!t || !out) return fail(STAG_E_INVALID, "null argument");
+    *out = nullptr;
+    if (t->n_nodes < 1 || t->n_features < 1) return fail(STAG_E_INVALID, "n_nodes and n_features must be positive");
+    if (!t->child_first || !t->row_kind || !t->intercept || !t->row_off || (t->n_keys > 0 && !t->tf))
+        return fail(STAG_E_INVALID, "null table pointer");
+    if (t->n_keys < 0 || t->n_tf < 0) return fail(STAG_E_INVALID, "negative rank-cut shape");
+    const int n = t->n_nodes;
+    if (t->child_first[n] != n || (n > 1 && t->child_first[0] != 1) || (n == 1 && t->child_first[0] != 1))
+        return fail(STAG_E_INVALID, "child_first is not a breadth-first numbering (child_first[0]=%d, child_first[n]=%d, n=%d)",
+                    t->child_first[0], t->child_first[n], n);
+    for (int i = 0; i < n; ++i)
+        if (t->child_first[i + 1] < t->child_first[i] || t->child_first[i] <= i)
+            return fail(STAG_E_INVALID, "child_first not monotone / not breadth-first at node %d", i);
+    int rc = check_device(device);
+    if (rc) return rc;
+
+    stag_db *db = new (std::nothrow) stag_db;
+    if (!db) return fail(STAG_E_NOMEM, "out of host memory");
+    db->device = device;
+    db->n_nodes = n;
+    db->L = t->n_features;
+    db->W = stag_words_per_row(t->n_features);
+    db->nchunks = (db->W + CHUNK_WORDS - 1) / CHUNK_WORDS;
+    db->n_keys = t->n_keys;
+    db->n_tf = t->n_tf;
+
+    // levels: [0,1) is the root; the children of a level's nodes are the next level
+    db->level_start = {0, 1};
+    for (;;) {
+        const int hi = db->level_start.back();
+        const int nhi = t->child_first[hi];  // == n when hi == n
+        if (hi >= n || nhi == hi) break;
+        db->level_start.push_back(nhi);
+    }
+    if (db->level_start.back() != n) {
+        delete db;
+        return fail(STAG_E_INVALID, "tree numbering does not cover all %d nodes (reached %d)", n, db->level_start.back());
+    }
+    db->max_depth = (int)db->level_start.size() - 2;  // levels whose nodes can have children
+    for (int d = 0; d < db->max_depth; ++d)
+        db->max_level_nodes = std::max(db->max_level_nodes, db->level_start[d + 1] - db->level_start[d]);
+
+    // per-parent error status and the set of rows that can ever be evaluated
+    std::vector<uint8_t> node_err(n, 0), evaluated(n, 0);
+    for (int p = 0; p < n; ++p) {
+        const int c0 = t->child_first[p], c1 = t->child_first[p + 1];
+        if (c1 - c0 < 2) continue;
+        for (int c = c0; c < c1; ++c) {
+            if (t->row_kind[c] == 1) { evaluated[c] = 1; continue; }
+            node_err[p] = t->row_kind[c] == 0 ? STAG_SEQ_MISSING_CLASSIFIER : STAG_SEQ_STRING_CLASSIFIER;
+            break;
+        }
+        if (node_err[p]) for (int c = c0; c < c1; ++c) evaluated[c] = 0;
+    }
+
+    // coefficient blocks
+    const int nch = db->nchunks;
+    std::vector<uint32_t> blk_off((size_t)n * nch + 1, 0);
+    std::vector<Entry> entries;
+    for (int c = 0; c < n; ++c) {
+        int64_t e = t->row_off[c];
+        const int64_t e1 = t->row_off[c + 1];
+        if (e1 < e) { delete db; return fail(STAG_E_INVALID, "row_off not monotone at node %d", c); }
+        int prev = -1;
+        for (int ch = 0; ch < nch; ++ch) {
+            blk_off[(size_t)c * nch + ch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
+            if (!evaluated[c]) continue;
+            const int64_t f_end = (int64_t)(ch + 1) * CHUNK_WORDS * 32;
+            while (e < e1 && t->row_feat[e] < f_end) {
+                const int f = t->row_feat[e];
+                if (f <= prev || f >= t->n_features) {
+                    delete db;
+                    return fail(STAG_E_INVALID, "row %d: feature %d out of order or out of range", c, f);
+                }
+                prev = f;
+                Entry en;
+                en.off = 4u * (uint32_t)((f >> 5) - ch * CHUNK_WORDS);
+                en.bit = (uint32_t)(f & 31);
+                en.w = t->row_w[e];
+                entries.push_back(en);
+                ++e;
+            }
+            while (entries.size() % BLOCK_ENTRIES) entries.push_back(Entry{0u, 0u, 0.0});
+        }
+        if (entries.size() / BLOCK_ENTRIES > 0x7fffffffull) { delete db; return fail(STAG_E_INVALID, "coefficient table too large"); }
+    }
+    blk_off[(size_t)n * nch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
+
+#define UP(buf, vec, T)                                                                              \
+    do {                                                                                             \
+        if ((rc = db->buf.reserve((vec).size()))) { db->free_all(); delete db; return rc; }          \
+        if (!(vec).empty() && hipMemcpy(db->buf.p, (vec).data(), (vec).size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) { \
+            db->free_all(); delete db; return fail(STAG_E_HIP, "upload of " #buf " failed");         \
+        }                                                                                            \
+        db->table_bytes += (int64_t)((vec).size() * sizeof(T));                                      \
+    } while (0)
+    std::vector<int32_t> cf(t->child_first, t->child_first + n + 1);
+    std::vector<double> ic(t->intercept, t->intercept + n);
+    std::vector<double> tfv(t->tf ? t->tf : nullptr, t->tf ? t->tf + (size_t)t->n_keys * (1 + t->n_tf) : nullptr);
+    UP(child_first, cf, int32_t);
+    UP(node_err, node_err, uint8_t);
+    UP(intercept, ic, double);
+    UP(blk_off, blk_off, uint32_t);
+    UP(tf, tfv, double);
+    static_assert(sizeof(Entry) == sizeof(uint4), "Entry must be 16 bytes");
+    if ((rc = db->blocks.reserve(entries.size()))) { db->free_all(); delete db; return rc; }
+    if (!entries.empty() && hipMemcpy(db->blocks.p, entries.data(), entries.size() * sizeof(Entry), hipMemcpyHostToDevice) != hipSuccess) {
+        db->free_all(); delete db; return fail(STAG_E_HIP, "upload of coefficient blocks failed");
+    }
+    db->table_bytes += (int64_t)(entries.size() * sizeof(Entry));
+#undef UP
+    *out = db;
+    return STAG_OK;
+}
+
+void stag_db_destroy(stag_db_t *db) {
+    if (!db) return;
+    (void)hipSetDevice(db->device);
+    db->free_all();
+    delete db;
+}
+
+int stag_db_info(const stag_db_t *db, int32_t *max_depth, int32_t *words_per_row, int32_t *n_keys, int64_t *table_bytes) {
+    if (!db) return fail(STAG_E_INVALID, "null db");
+    if (max_depth) *max_depth = std::max(db->max_depth, 1);
+    if (words_per_row) *words_per_row = db->W;
+    if (n_keys) *n_keys = db->n_keys;
+    if (table_bytes) *table_bytes = db->table_bytes;
+    return STAG_OK;
+}
+
+int stag_db_reserve(stag_db_t *db, int64_t n, int64_t text_bytes) {
+    if (!db || n < 0 || text_bytes < 0) return fail(STAG_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(db->device));
+    int rc;
+    if ((rc = reserve_walk(db, n))) return rc;
+    if (text_bytes > 0) {
+        if ((rc = db->bits.reserve((size_t)n * db->W))) return rc;
+        if ((rc = db->enc_n_char.reserve(n))) return rc;
+        if ((rc = db->enc_status.reserve(n))) return rc;
+    }
+    return STAG_OK;
+}
+
+int stag_encode_a2m_dev(int32_t n_features, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
+                        double min_perc_state, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned,
+                        int32_t *d_status, void *stream) {
+    if (n < 0 || n_features < 1 || (n > 0 && (!d_text || !d_offs || !d_bits || !d_n_char || !d_n_aligned || !d_status)))
+        return fail(STAG_E_INVALID, "bad argument");
+    return encode_dev(nullptr, n_features, d_text, text_bytes, d_offs, n, min_perc_state, d_bits, d_n_char, d_n_aligned,
+                      d_status, (hipStream_t)stream);
+}
+
+int stag_encode_a2m(int32_t device, int32_t n_features, const char *text, const int64_t *offs, int64_t n,
+                    double min_perc_state, uint32_t *bits, int32_t *n_char, int32_t *n_aligned, int32_t *status) {
+    if (n < 0 || n_features < 1 || (n > 0 && (!text || !offs || !bits || !n_char || !n_aligned || !status)))
+        return fail(STAG_E_INVALID, "bad argument");
+    int rc = check_device(device);
+    if (rc || n == 0) return rc;
+    const int W = stag_words_per_row(n_features);
+    const int64_t text_bytes = offs[n];
+    if (offs[0] < 0 || text_bytes < offs[0]) return fail(STAG_E_INVALID, "offs must be non-decreasing");
+    DevBuf<uint8_t> d_text;
+    DevBuf<int64_t> d_offs;
+    DevBuf<uint32_t> d_bits;
+    DevBuf<int32_t> d_i;
+    auto done = [&](int code) { d_text.release(); d_offs.release(); d_bits.release(); d_i.release(); return code; };
+    if ((rc = d_text.reserve(text_bytes + 16)) || (rc = d_offs.reserve(n + 1)) || (rc = d_bits.reserve((size_t)n * W)) ||
+        (rc = d_i.reserve(3 * n)))
+        return done(rc);
+    if (hipMemcpy(d_text.p, text, text_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
+        return done(fail(STAG_E_HIP, "host to device copy failed"));
+    rc = encode_dev(nullptr, n_features, (const char *)d_text.p, text_bytes, d_offs.p, n, min_perc_state, d_bits.p, d_i.p,
+                    d_i.p + n, d_i.p + 2 * n, nullptr);
+    if (rc) return done(rc);
+    if (hipMemcpy(bits, d_bits.p, (size_t)n * W * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(n_char, d_i.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(n_aligned, d_i.p + n, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(status, d_i.p + 2 * n, n * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(STAG_E_HIP, "device to host copy failed: %s", hipGetErrorString(hipGetLastError())));
+    return done(STAG_OK);
+}
+
+int stag_classify_bits_dev(stag_db_t *db, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in,
+                           const stag_results_t *d_out, void *stream) {
+    if (!db || n < 0 || (n > 0 && !d_bits)) return fail(STAG_E_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(db->device));
+    int rc = reserve_walk(db, n);
+    if (rc) return rc;
+    return walk_dev(db, d_bits, n, d_status_in, resolve(db, d_out), true, (hipStream_t)stream);
+}
+
+int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int32_t *status_in,
+                       const stag_results_t *out) {
+    if (!db || n < 0 || !out || (n > 0 && (!bits || !out->status))) return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    int rc;
+    if ((rc = reserve_walk(db, n)) || (rc = db->bits.reserve((size_t)n * db->W)) || (rc = db->enc_status.reserve(n)))
+        return rc;
+    HIP_TRY(hipMemcpy(db->bits.p, bits, (size_t)n * db->W * 4, hipMemcpyHostToDevice));
+    if (status_in) HIP_TRY(hipMemcpy(db->enc_status.p, status_in, n * 4, hipMemcpyHostToDevice));
+    if ((rc = walk_dev(db, db->bits.p, n, status_in ? db->enc_status.p : nullptr, resolve(db, nullptr), true, nullptr)))
+        return rc;
+    return copy_results_to_host(db, out, n, nullptr);
+}
+
+int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
+                          double min_perc_state, const stag_results_t *d_out, void *stream) {
+    if (!db || n < 0 || (n > 0 && (!d_text || !d_offs))) return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    int rc;
+    if ((rc = stag_db_reserve(db, n, std::max<int64_t>(text_bytes, 1)))) return rc;
+    const Out o = resolve(db, d_out);
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = encode_dev(db, db->L, d_text, text_bytes, d_offs, n, min_perc_state, db->bits.p, db->enc_n_char.p,
+                         o.n_aligned, db->enc_status.p, st)))
+        return rc;
+    return walk_dev(db, db->bits.p, n, db->enc_status.p, o, false, st);
+}
+
+int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n, double min_perc_state,
+                      const stag_results_t *out, uint32_t *bits_out, int32_t *n_char_out) {
+    if (!db || n < 0 || !out || (n > 0 && (!text || !offs || !out->status))) return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    const int64_t text_bytes = offs[n];
+    if (offs[0] < 0 || text_bytes < offs[0]) return fail(STAG_E_INVALID, "offs must be non-decreasing");
+    int rc;
+    if ((rc = stag_db_reserve(db, n, std::max<int64_t>(text_bytes, 1))) || (rc = db->text.reserve(text_bytes + 16)) ||
+        (rc = db->offs.reserve(n + 1)))
+        return rc;
+    HIP_TRY(hipMemcpy(db->text.p, text, text_bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if ((rc = stag_classify_a2m_dev(db, (const char *)db->text.p, text_bytes, db->offs.p, n, min_perc_state, nullptr,
+                                    nullptr)))
+        return rc;
+    if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;
+    if (bits_out) HIP_TRY(hipMemcpy(bits_out, db->bits.p, (size_t)n * db->W * 4, hipMemcpyDeviceToHost));
+    if (n_char_out) HIP_TRY(hipMemcpy(n_char_out, db->enc_n_char.p, n * 4, hipMemcpyDeviceToHost));
+    return STAG_OK;
+}
+
+int stag_backtranslate(const char *prot, int64_t prot_len, const char *gene, int64_t gene_len, int32_t check_length,
+                       char *out, int64_t *out_len) {
+    if (!prot || !gene || !out || !out_len || prot_len < 0 || gene_len < 0) return fail(STAG_E_INVALID, "bad argument");
+    int64_t residues = 0;
+    for (int64_t i = 0; i < prot_len; ++i) residues += prot[i] != '-';
+    if (check_length && gene_len != 3 * residues && gene_len - 3 != 3 * residues) {
+        *out_len = -1;
+        return STAG_OK;
+    }
+    int64_t g = 0, o = 0;
+    for (int64_t i = 0; i < prot_len; ++i) {
+        const unsigned char c = (unsigned char)prot[i];
+        if (c == '-') {
+            out[o++] = '-'; out[o++] = '-'; out[o++] = '-';
+        } else if (c >= 'A' && c <= 'Z') {
+            for (int64_t j = g; j < g + 3 && j < gene_len; ++j) out[o++] = gene[j];
+            g += 3;
+        } else if (c >= 'a' && c <= 'z') {
+            g += 3;
+        }
+    }
+    *out_len = o;
+    return STAG_OK;
+}
+
+int stag_profile_enable(stag_db_t *db, int32_t on) {
+    if (!db) return fail(STAG_E_INVALID, "null db");
+    db->prof = on != 0;
+    return STAG_OK;
+}
+
+int stag_profile_read(stag_db_t *db, double *ms_per_class, int64_t *launches_per_class) {
+    if (!db || !ms_per_class || !launches_per_class) return fail(STAG_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(db->device));
+    HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < STAG_PROF_CLASSES; ++i) { ms_per_class[i] = 0.0; launches_per_class[i] = 0; }
+    for (auto &r : db->recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            ms_per_class[r.cls] += ms;
+            launches_per_class[r.cls] += 1;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    db->recs.clear();
+    return STAG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,441 @@
+// Device kernels of libstag_hip.so (gfx950 / MI355X only).  Included once by stag_hip.hip.
+//
+// Data layout in HBM
+//   packed rows   uint32[n][W]   bit f of sequence i = one-hot feature f (word f>>5, bit f&31),
+//                                W = ceil(L/32) rounded up to 4 words (16-byte rows)
+//   coefficient blocks           each child row's NON-ZERO coefficients, sorted by feature, cut
+//                                at CHUNK_WORDS-word boundaries and padded per (row, chunk) to
+//                                blocks of 4 entries {byte offset, bit, fp64 w} = 64 B, so that one
+//                                s_load_dwordx16 fetches a block into SGPRs for a whole wave
+//   grouping      node[n], pos[n], order[n], tasks[]: sequences sorted by current tree node,
+//                                cut into tasks of <= 64 sequences of one node
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace stagk {
+
+constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
+constexpr int NW = 4;             // waves per walk workgroup
+constexpr int CHUNK_WORDS = 240;  // packed-row words staged in LDS per pass (7,680 features)
+constexpr int ROW_STRIDE = CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
+constexpr int CB = 4;             // sibling rows scored per pass
+constexpr int BLOCK_ENTRIES = 4;
+
+struct Entry {      // 16 bytes
+    uint32_t off;   // byte offset of the feature's word inside the staged chunk of a row
+    uint32_t bit;   // feature & 31
+    double w;       // 0.0 for padding entries
+};
+
+// Read-only tables are addressed through the constant address space: a wave-uniform address
+// then compiles to s_load_* (one fetch per wave into SGPRs) instead of a 64-lane vector load.
+#define STAG_CONST __attribute__((address_space(4)))
+template <typename T>
+__device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
+    return (const T STAG_CONST *)(uintptr_t)p;
+}
+
+struct Task {
+    int32_t node, start, count, pad;
+};
+// plain vector types: unlike HIP's uint4 class they can be loaded from the constant address space
+using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
+using i32x4 = __attribute__((ext_vector_type(4))) int32_t;
+
+// ------------------------------------------------------------------------------------------
+// encode: stag/align.py:28-58 (+ the filter of :160).  One wave per aligned string.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ text, int64_t text_bytes,
+                                                    const int64_t *__restrict__ offs, int64_t n, int L, int W,
+                                                    double min_perc, uint32_t *__restrict__ rows,
+                                                    int32_t *__restrict__ n_char_out,
+                                                    int32_t *__restrict__ n_aligned_out,
+                                                    int32_t *__restrict__ status_out) {
+    extern __shared__ uint32_t s_enc[];  // 4 waves x W words
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t seq = (int64_t)blockIdx.x * 4 + wave;
+    if (seq >= n) return;  // whole wave leaves; no workgroup barrier below
+    uint32_t *row = s_enc + (size_t)wave * W;
+    for (int w = lane; w < W; w += 64) row[w] = 0;
+
+    const int64_t begin = offs[seq], end = offs[seq + 1];
+    const int64_t base = begin & ~(int64_t)15;
+    int running = 0, aligned = 0;
+    for (int64_t p0 = base; p0 < end; p0 += 1024) {
+        const int64_t p = p0 + (int64_t)lane * 16;
+        uint32_t wv[4] = {0, 0, 0, 0};
+        if (p < end) {
+            if (p + 16 <= text_bytes) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
+                wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+            } else {
+                for (int j = 0; j < 16 && p + j < text_bytes; ++j)
+                    wv[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
+            }
+        }
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+        int k = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const uint32_t b = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
+            const int64_t q = p + j;
+            const bool valid = q >= begin && q < end;
+            const bool skip = (b - (uint32_t)'a' < 26u) || b == '\n' || b == '\r';
+            const int code = b == 'A' ? 4 : b == 'C' ? 3 : b == 'G' ? 2 : (b == 'T' || b == 'U') ? 1 : 0;
+            if (valid && !skip) {
+                const int bit = 5 * k + code;
+                if (bit < 64) lo |= 1ull << bit; else hi |= 1u << (bit - 64);
+                ++k;
+                aligned += code != 0;
+            }
+        }
+        const int incl = wave_incl_scan(k, lane);
+        const int total = __shfl(incl, 63);
+        const int64_t bitoff = 5ll * (running + incl - k);
+        const int word0 = (int)(bitoff >> 5);
+        const int sh = (int)(bitoff & 31);
+        const uint64_t a = lo << sh;
+        const uint64_t carry = sh ? lo >> (64 - sh) : 0ull;
+        const uint64_t bb = ((uint64_t)hi << sh) | carry;
+        const uint32_t v4[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bb, (uint32_t)(bb >> 32)};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (v4[i] && word0 + i < W) atomicOr(&row[word0 + i], v4[i]);
+        running += total;
+    }
+    aligned = wave_sum(aligned);
+    uint32_t *dst = rows + (size_t)seq * W;
+    for (int w = lane * 4; w < W; w += 256) {
+        uint4 v;
+        v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
+        *reinterpret_cast<uint4 *>(dst + w) = v;
+    }
+    if (lane == 0) {
+        int st = 0;  // STAG_SEQ_OK
+        if (running == 0) st = 5;
+        else if (!((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
+        else if ((int64_t)running * 5 != L) st = 7;
+        n_char_out[seq] = running;
+        n_aligned_out[seq] = aligned;
+        status_out[seq] = st;
+    }
+}
+
+// find_n_aligned_characters (classify.py:79-87) for rows that did not come from k_encode_a2m.
+__global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restrict__ rows, int64_t n, int L, int W,
+                                                       int32_t *__restrict__ n_aligned) {
+    const int lane = threadIdx.x & 63;
+    const int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (seq >= n) return;
+    const uint32_t *row = rows + (size_t)seq * W;
+    int gaps = 0;
+    for (int w = lane; w < W; w += 64) {
+        const int s = (5 - (int)((32ll * w) % 5)) % 5;  // first bit of this word that is bit 0 of a column
+        gaps += __popc(row[w] & (uint32_t)(0x1084210842108421ull << s));
+    }
+    gaps = wave_sum(gaps);
+    if (lane == 0) n_aligned[seq] = (L + 4) / 5 - gaps;
+}
+
+// ------------------------------------------------------------------------------------------
+// grouping by current node
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_walk(int64_t n, int D, const int32_t *__restrict__ status_in,
+                                                   int32_t *__restrict__ status, int32_t *__restrict__ node,
+                                                   int32_t *__restrict__ path_node, int32_t *__restrict__ path_len) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int st = status_in ? status_in[s] : 0;
+    status[s] = st;
+    node[s] = st == 0 ? 0 : -1;
+    path_len[s] = 0;
+    for (int d = 0; d < D; ++d) path_node[s * D + d] = -1;
+}
+
+// pos[s] = rank of s among the sequences of its node, count[node] = sequences at that node.
+// One returning atomic per (wave, distinct node) instead of one per sequence.
+__global__ __launch_bounds__(256) void k_assign(int64_t n, const int32_t *__restrict__ node,
+                                                int32_t *__restrict__ count, int32_t *__restrict__ pos) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int nd = s < n ? node[s] : -1;
+    bool todo = nd >= 0;
+    int my_pos = 0;
+    for (;;) {
+        const unsigned long long pending = __ballot(todo);
+        if (!pending) break;
+        const int leader = __ffsll((long long)pending) - 1;
+        const int n0 = __shfl(nd, leader);
+        const bool mine = todo && nd == n0;
+        const unsigned long long same = __ballot(mine);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&count[n0], __popcll(same));
+        base = __shfl(base, leader);
+        if (mine) {
+            my_pos = base + __popcll(same & ((1ull << lane) - 1ull));
+            todo = false;
+        }
+    }
+    if (nd >= 0) pos[s] = my_pos;
+}
+
+// One workgroup: exclusive scans over the nodes [lo, hi) of one level.
+__global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32_t *__restrict__ count,
+                                                     int32_t *__restrict__ node_off, int32_t *__restrict__ task_off,
+                                                     int32_t *__restrict__ n_tasks) {
+    __shared__ int s_a[1024], s_b[1024];
+    __shared__ int s_carry[2];
+    const int t = threadIdx.x;
+    if (t == 0) { s_carry[0] = 0; s_carry[1] = 0; }
+    __syncthreads();
+    for (int base = lo; base < hi; base += 1024) {
+        const int i = base + t;
+        const int c = i < hi ? count[i] : 0;
+        const int k = (c + TILE - 1) / TILE;
+        s_a[t] = c;
+        s_b[t] = k;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            const int va = t >= d ? s_a[t - d] : 0;
+            const int vb = t >= d ? s_b[t - d] : 0;
+            __syncthreads();
+            s_a[t] += va;
+            s_b[t] += vb;
+            __syncthreads();
+        }
+        if (i < hi) {
+            node_off[i] = s_carry[0] + s_a[t] - c;
+            task_off[i] = s_carry[1] + s_b[t] - k;
+        }
+        __syncthreads();
+        if (t == 1023) { s_carry[0] += s_a[t]; s_carry[1] += s_b[t]; }
+        __syncthreads();
+    }
+    if (t == 0) *n_tasks = s_carry[1];
+}
+
+__global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
+                                                 const int32_t *__restrict__ pos, const int32_t *__restrict__ count,
+                                                 const int32_t *__restrict__ node_off,
+                                                 const int32_t *__restrict__ task_off, int32_t *__restrict__ order,
+                                                 Task *__restrict__ tasks) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int nd = node[s];
+    if (nd < lo || nd >= hi) return;
+    const int p = pos[s];
+    const int at = node_off[nd] + p;
+    order[at] = (int32_t)s;
+    if ((p & (TILE - 1)) == 0) {
+        Task tk;
+        tk.node = nd; tk.start = at; tk.count = min(TILE, count[nd] - p); tk.pad = 0;
+        tasks[task_off[nd] + p / TILE] = tk;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// walk: one tree level.  stag/classify.py:22-52 for all sequences standing at nodes of level
+// `depth`.  One workgroup = up to 64 sequences of ONE node (lane = sequence): their packed
+// rows are staged in LDS, the siblings' non-zero coefficients arrive as wave-uniform scalar
+// loads and every lane adds the coefficients whose feature bit is set in its own row.
+// ------------------------------------------------------------------------------------------
+struct WalkArgs {
+    const uint32_t *bits;       // [n][W]
+    int W, nchunks, depth, D;
+    const int32_t *n_tasks;
+    const Task *tasks;
+    const int32_t *order;
+    const int32_t *child_first;
+    const uint8_t *node_err;    // per parent: status every sequence reaching it gets (0 = fine)
+    const double *intercept;
+    const uint32_t *blk_off;    // [n_nodes*nchunks + 1]
+    const uint4 *blocks;        // Entry[4] per block
+    int32_t *node;              // [n] in: current node; out: next node or -1
+    int32_t *path_node;         // [n][D]
+    double *path_prob;          // [n][D]  (2.0 = "single child" placeholder, classify.py:37)
+    int32_t *path_len;
+    int32_t *status;
+};
+
+__device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
+
+// e = {off, bit, w_lo, w_hi} in SGPRs; returns w if this lane's row has the feature, else +0.0
+__device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 e) {
+    const uint32_t x = *reinterpret_cast<const uint32_t *>(my_row + e.x);
+    const int m = __builtin_amdgcn_sbfe((int)x, e.y, 1u);  // 0 or -1
+    return __hiloint2double((int)e.w & m, (int)e.z & m);
+}
+
+__global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
+    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
+    __shared__ double s_z[NW][CB][TILE];
+    __shared__ double s_p[CB][TILE];
+
+    if ((int)blockIdx.x >= *as_const(a.n_tasks)) return;
+    const i32x4 tkv = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];
+    Task tk;
+    tk.node = tkv.x; tk.start = tkv.y; tk.count = tkv.z; tk.pad = 0;
+    const int32_t STAG_CONST *child_first = as_const(a.child_first);
+    const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
+    const u32x4 STAG_CONST *blocks = as_const(reinterpret_cast<const u32x4 *>(a.blocks));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int seq = lane < tk.count ? a.order[tk.start + lane] : -1;
+    const int c0 = child_first[tk.node];
+    const int k = child_first[tk.node + 1] - c0;
+
+    if (k == 1 || a.node_err[tk.node]) {  // nothing to score (classify.py:35-37) or the reference raises
+        if (wave == 0 && seq >= 0) {
+            if (k == 1) {
+                a.path_node[(size_t)seq * a.D + a.depth] = c0;
+                a.path_prob[(size_t)seq * a.D + a.depth] = 2.0;
+                a.path_len[seq] = a.depth + 1;
+                a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
+            } else {
+                a.status[seq] = a.node_err[tk.node];
+                a.node[seq] = -1;
+            }
+        }
+        return;
+    }
+
+    double best_p = -1.0;
+    int best_c = -1;
+    const char *my_row = reinterpret_cast<const char *>(s_rows + lane * ROW_STRIDE);
+
+    for (int cb = 0; cb < k; cb += CB) {
+        const int kb = min(CB, k - cb);
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            const int cw = min(CHUNK_WORDS, a.W - ch * CHUNK_WORDS);
+            const int q = cw >> 2;
+            __syncthreads();  // everyone is done reading the previous chunk
+#pragma unroll 4
+            for (int r = wave; r < TILE; r += NW) {
+                const int s = __shfl(seq, r);  // wave-uniform
+                for (int j = lane; j < q; j += 64) {
+                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                    if (s >= 0)
+                        v = *reinterpret_cast<const uint4 *>(a.bits + (size_t)s * a.W + ch * CHUNK_WORDS + 4 * j);
+                    uint32_t *d = s_rows + r * ROW_STRIDE + 4 * j;
+                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+                }
+            }
+            __syncthreads();
+            for (int ci = 0; ci < kb; ++ci) {
+                const uint32_t seg = (uint32_t)(c0 + cb + ci) * a.nchunks + ch;
+                const uint32_t b0 = blk_off[seg], b1 = blk_off[seg + 1];
+                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+                for (uint32_t b = b0 + wave; b < b1; b += NW) {
+                    const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
+                    const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    z0 += masked_weight(my_row, e0);
+                    z1 += masked_weight(my_row, e1);
+                    z2 += masked_weight(my_row, e2);
+                    z3 += masked_weight(my_row, e3);
+                }
+                const double z = (z0 + z1) + (z2 + z3);
+                if (ch == 0) s_z[wave][ci][lane] = z; else s_z[wave][ci][lane] += z;
+            }
+        }
+        __syncthreads();
+        for (int ci = wave; ci < kb; ci += NW) {
+            double z = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) z += s_z[w][ci][lane];
+            s_p[ci][lane] = sigmoid(z + as_const(a.intercept)[c0 + cb + ci]);
+        }
+        __syncthreads();
+        if (wave == 0) {
+            for (int ci = 0; ci < kb; ++ci) {
+                const double p = s_p[ci][lane];
+                if (p > best_p) { best_p = p; best_c = c0 + cb + ci; }  // strict '>' in stored order
+            }
+        }
+    }
+    if (wave == 0 && seq >= 0) {
+        if (best_c >= 0) {
+            a.path_node[(size_t)seq * a.D + a.depth] = best_c;
+            a.path_prob[(size_t)seq * a.D + a.depth] = best_p;
+            a.path_len[seq] = a.depth + 1;
+            a.node[seq] = a.child_first[best_c + 1] > a.child_first[best_c] ? best_c : -1;
+        } else {
+            a.node[seq] = -1;  // every probability was NaN: the reference stops here (classify.py:49)
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rank cut: classify.py:106-110 (placeholder fix-up) and :58-72 (find_correct_level)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int K, int n_tf, const double *__restrict__ tf,
+                                                 const int32_t *__restrict__ path_len, double *__restrict__ path_prob,
+                                                 int32_t *__restrict__ n_lead_single, double *__restrict__ level_prob,
+                                                 int32_t *__restrict__ selected, int32_t *__restrict__ status) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    int sel = -1, lead = 0;
+    int st = status[s];
+    const int len = path_len[s];
+    double *pp = path_prob + (size_t)s * D;
+    double *lp = level_prob + (size_t)s * K;
+    for (int kk = 0; kk < K; ++kk) lp[kk] = 0.0;
+    if (st == 0 && len == 0) st = 4;  // perc[0] on an empty list
+    if (st == 0) {
+        bool leading = true;
+        for (int i = 0; i < len; ++i) {
+            double p = pp[i];
+            if (p == 2.0) {
+                p = i == 0 ? 1.0 : pp[i - 1];
+                pp[i] = p;
+                if (leading) ++lead;
+            } else {
+                leading = false;
+            }
+        }
+        for (int i = len; i < D; ++i) pp[i] = 0.0;
+        double best = 0.0;
+        for (int kk = 0; kk < K; ++kk) {
+            const double *row = tf + (size_t)kk * (1 + n_tf);
+            double acc = 0.0;
+            if (len == n_tf) {
+                for (int i = 0; i < len; ++i) acc += row[1 + i] * pp[i];
+            } else if (len == 1) {
+                for (int i = 0; i < n_tf; ++i) acc += row[1 + i] * pp[0];
+            } else if (n_tf == 1) {
+                for (int i = 0; i < len; ++i) acc += row[1] * pp[i];
+            } else {
+                st = 3;
+                break;
+            }
+            const double p = sigmoid(acc + row[0]);
+            lp[kk] = p;
+            if (p > best) { best = p; sel = kk; }
+        }
+        if (st != 0) sel = -1;
+    } else {
+        for (int i = 0; i < D; ++i) pp[i] = 0.0;
+    }
+    n_lead_single[s] = lead;
+    selected[s] = sel;
+    status[s] = st;
+}
+
+}  // namespace stagk

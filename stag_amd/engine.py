@@ -1,0 +1,203 @@
+"""Device-resident database + batch classification through the C ABI (include/stag_hip.h).
+
+``Database`` is the packed, GPU-resident form of what ``load_db`` returns; ``classify_*``
+run the HIP kernels on a batch and return plain NumPy arrays; ``result_rows`` turns them
+into the reference's 7 output fields (stag/classify.py:116-122).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .tables import PackedTables, pack_bool_rows, pack_db, pack_text
+
+# the exception the reference raises for each per-sequence status (include/stag_hip.h)
+_EXC = {
+    _lib.SEQ_MISSING_CLASSIFIER: (KeyError, "classifier missing for a sibling (stag/classify.py:40)"),
+    _lib.SEQ_STRING_CLASSIFIER: (TypeError, "'no_negative_examples' classifier evaluated (stag/classify.py:24-25)"),
+    _lib.SEQ_RANKCUT_SHAPE: (ValueError, "operands could not be broadcast together in the rank cut (stag/classify.py:25)"),
+    _lib.SEQ_EMPTY_PATH: (IndexError, "list index out of range: empty path (stag/classify.py:106)"),
+    _lib.SEQ_ZERO_COLUMNS: (ZeroDivisionError, "division by zero: no alignment column (stag/align.py:58)"),
+    _lib.SEQ_LENGTH_MISMATCH: (ValueError, "operands could not be broadcast together: alignment length differs "
+                                          "from the database's (stag/classify.py:25)"),
+}
+
+
+def raise_for_status(status, ids=None):
+    """Raise what the reference would have raised at the first failing sequence (it processes
+    sequences in order and does not catch)."""
+    bad = np.flatnonzero((status != _lib.SEQ_OK) & (status != _lib.SEQ_FILTERED))
+    if bad.size:
+        i = int(bad[0])
+        exc, msg = _EXC[int(status[i])]
+        raise exc("%s [sequence %s]" % (msg, ids[i] if ids is not None else i))
+
+
+class BatchResult:
+    def __init__(self, n, D, K):
+        self.n, self.D, self.K = n, D, K
+        self.path_node = np.full((n, D), -1, dtype=np.int32)
+        self.path_prob = np.zeros((n, D), dtype=np.float64)
+        self.path_len = np.zeros(n, dtype=np.int32)
+        self.n_lead_single = np.zeros(n, dtype=np.int32)
+        self.level_prob = np.zeros((n, max(K, 1)), dtype=np.float64)
+        self.selected = np.full(n, -1, dtype=np.int32)
+        self.n_aligned = np.zeros(n, dtype=np.int32)
+        self.status = np.zeros(n, dtype=np.int32)
+        self.bits = None
+        self.n_char = None
+
+    def as_struct(self):
+        r = _lib.Results()
+        for f, _ in _lib.Results._fields_:
+            setattr(r, f, _lib.ptr(getattr(self, f)))
+        return r
+
+
+class Database:
+    """A single-gene stagDB resident on one GPU."""
+
+    def __init__(self, tables, device=0):
+        if not isinstance(tables, PackedTables):
+            raise TypeError("tables must be PackedTables (see stag_amd.tables.pack_db)")
+        self.tables = tables
+        self.device = int(device)
+        self._h = ctypes.c_void_p()
+        st = tables.as_struct()
+        _lib.check(_lib.lib().stag_db_create(ctypes.byref(st), self.device, ctypes.byref(self._h)))
+        d, w, k, tb = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int64()
+        _lib.check(_lib.lib().stag_db_info(self._h, ctypes.byref(d), ctypes.byref(w), ctypes.byref(k), ctypes.byref(tb)))
+        self.max_depth, self.words_per_row, self.n_keys, self.table_bytes = d.value, w.value, k.value, tb.value
+        self.names = tables.names
+        self.keys = tables.keys
+        self.n_features = tables.n_features
+        self._lineage_cache = {}
+
+    @classmethod
+    def from_dicts(cls, taxonomy, tax_function, classifiers, n_features=None, device=0):
+        return cls(pack_db(taxonomy, tax_function, classifiers, n_features), device)
+
+    @property
+    def handle(self):
+        if not self._h:
+            raise _lib.StagError("database handle already closed")
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.lib().stag_db_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ------------------------------------------------------------------ host-buffer calls
+    def encode_a2m(self, strings, min_perc_state=0.0):
+        """align.py:37-58 for a list of aligned strings -> (bits[n,W], n_char, n_aligned, status)."""
+        text, offs = pack_text(strings)
+        n = len(strings)
+        bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
+        n_char = np.zeros(n, dtype=np.int32)
+        n_al = np.zeros(n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        _lib.check(_lib.lib().stag_encode_a2m(self.device, self.n_features, _lib.ptr(text), _lib.ptr(offs), n,
+                                              float(min_perc_state), _lib.ptr(bits), _lib.ptr(n_char),
+                                              _lib.ptr(n_al), _lib.ptr(status)))
+        return bits, n_char, n_al, status
+
+    def classify_bits(self, bits, status_in=None):
+        """classify_seq (classify.py:94-124) for packed rows uint32[n, words_per_row]."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint32)
+        if bits.ndim != 2 or bits.shape[1] != self.words_per_row:
+            raise ValueError("bits must be [n, %d] uint32" % self.words_per_row)
+        n = bits.shape[0]
+        res = BatchResult(n, self.max_depth, self.n_keys)
+        st = res.as_struct()
+        sin = None if status_in is None else np.ascontiguousarray(status_in, dtype=np.int32)
+        _lib.check(_lib.lib().stag_classify_bits(self.handle, _lib.ptr(bits), n, _lib.ptr(sin), ctypes.byref(st)))
+        res.level_prob = res.level_prob[:, :self.n_keys]
+        return res
+
+    def classify_onehot(self, X):
+        """X: bool [n, L] exactly as the reference holds it."""
+        X = np.asarray(X)
+        if X.ndim != 2:
+            raise ValueError("X must be [n, L]")
+        if X.shape[1] != self.n_features:
+            status = np.full(X.shape[0], _lib.SEQ_LENGTH_MISMATCH, dtype=np.int32)
+            bits = np.zeros((X.shape[0], self.words_per_row), dtype=np.uint32)
+            res = self.classify_bits(bits, status)
+            ncols = (X.shape[1] + 4) // 5
+            res.n_aligned = (ncols - X[:, 0::5].sum(axis=1)).astype(np.int32)
+            return res
+        return self.classify_bits(pack_bool_rows(X, self.words_per_row))
+
+    def classify_a2m(self, strings, min_perc_state=0.0, want_bits=False):
+        """encode + classify on the GPU; rows never leave it unless want_bits."""
+        text, offs = pack_text(strings)
+        n = len(strings)
+        res = BatchResult(n, self.max_depth, self.n_keys)
+        st = res.as_struct()
+        res.n_char = np.zeros(n, dtype=np.int32)
+        if want_bits:
+            res.bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
+        _lib.check(_lib.lib().stag_classify_a2m(self.handle, _lib.ptr(text), _lib.ptr(offs), n, float(min_perc_state),
+                                                ctypes.byref(st), _lib.ptr(res.bits), _lib.ptr(res.n_char)))
+        res.level_prob = res.level_prob[:, :self.n_keys]
+        return res
+
+    # ------------------------------------------------------------------ profiling (bench.py)
+    def profile_enable(self, on=True):
+        _lib.check(_lib.lib().stag_profile_enable(self.handle, int(bool(on))))
+
+    def profile_read(self):
+        ms = np.zeros(len(_lib.PROF_CLASSES), dtype=np.float64)
+        cnt = np.zeros(len(_lib.PROF_CLASSES), dtype=np.int64)
+        _lib.check(_lib.lib().stag_profile_read(self.handle, _lib.ptr(ms), _lib.ptr(cnt)))
+        return {k: (float(m), int(c)) for k, m, c in zip(_lib.PROF_CLASSES, ms, cnt)}
+
+    def reserve(self, n, text_bytes=0):
+        _lib.check(_lib.lib().stag_db_reserve(self.handle, int(n), int(text_bytes)))
+
+    # ------------------------------------------------------------------ output fields
+    def lineage(self, res, i):
+        """(tax list) for sequence i; cached per end position because a position fixes its path."""
+        n = int(res.path_len[i])
+        if n == 0:
+            return []
+        key = int(res.path_node[i, n - 1])
+        tax = self._lineage_cache.get(key)
+        if tax is None:
+            tax = [self.names[j] for j in res.path_node[i, :n]]
+            self._lineage_cache[key] = tax
+        return tax
+
+    def result_row(self, res, i, gene_id, long_out=True):
+        """The reference's output fields for sequence i (classify.py:116-122)."""
+        tax = self.lineage(res, i)
+        sel = int(res.selected[i])
+        selected = self.keys[sel] if sel >= 0 else -1        # int -1 when nothing was selected (:61)
+        assigned = ";".join(tax[0:int(selected) + 1])
+        if not long_out:
+            return [gene_id, assigned]
+        n = len(tax)
+        lead = int(res.n_lead_single[i])
+        perc = ["1"] * min(lead, n) + [repr(float(p)) for p in res.path_prob[i, lead:n]]
+        per_level = [k + ":" + repr(float(p)) for k, p in zip(self.keys, res.level_prob[i])]
+        return [gene_id, assigned, "/".join(tax), selected, "/".join(perc), "/".join(per_level),
+                str(int(res.n_aligned[i]))]
+
+    def result_rows(self, res, ids, long_out=True):
+        """Rows for every sequence the reference would have yielded (status FILTERED is skipped);
+        raises the reference's exception for the first failing sequence."""
+        raise_for_status(res.status, ids)
+        return [self.result_row(res, i, ids[i], long_out) for i in range(res.n) if res.status[i] == _lib.SEQ_OK]

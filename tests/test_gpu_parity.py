@@ -1,0 +1,292 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the reference's
+golden vectors.  Bit-exact for encodings, ids, counts and text; 1e-9 relative for
+probabilities (north_star); lineage identical unless the oracle's own margin at the first
+differing level is below that tolerance."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from oracle import oracle_c, oracle_np
+from stag_amd import _lib, tables
+from stag_amd.engine import Database, raise_for_status
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-9
+
+
+def encode_raw(strings, L):
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    W = _lib.lib().stag_words_per_row(L)
+    bits = np.zeros((n, W), dtype=np.uint32)
+    n_char, n_al, status = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    _lib.check(_lib.lib().stag_encode_a2m(0, L, _lib.ptr(text), _lib.ptr(offs), n, 0.0, _lib.ptr(bits),
+                                          _lib.ptr(n_char), _lib.ptr(n_al), _lib.ptr(status)))
+    return bits, n_char, n_al, status
+
+
+def test_encode_golden_bit_exact():
+    cases = gu.load("encode.json")
+    L = 5 * max(len(c["a2m"]) for c in cases)
+    bits, n_char, n_al, status = encode_raw([c["a2m"] for c in cases], L)
+    dense = tables.unpack_rows(bits, bits.shape[1] * 32)
+    for i, c in enumerate(cases):
+        if "error" in c:
+            assert status[i] == _lib.SEQ_ZERO_COLUMNS and n_char[i] == 0
+            assert not dense[i].any()
+            continue
+        exp = gu.bits(c["bits"])
+        assert n_char[i] * 5 == len(exp)
+        assert np.array_equal(dense[i, :len(exp)], exp), c["a2m"]
+        assert not dense[i, len(exp):].any()
+        assert n_al[i] / n_char[i] * 100 == float(c["pct"])
+        assert status[i] in (_lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH)
+
+
+def test_encode_random_vs_oracle_with_filter_and_newlines():
+    rng = np.random.default_rng(5)
+    ncol = 300
+    alphabet = np.array(list("ACGTU-.NRY*acgtn"))
+    p = np.array([8, 8, 8, 8, 2, 10, 1, 1, 1, 1, 0.5] + [0.6] * 5)
+    p /= p.sum()
+    strings, clean = [], []
+    for i in range(500):
+        s = "".join(rng.choice(alphabet, size=int(rng.integers(1, 700)), p=p))
+        clean.append(s)
+        if i % 3 == 0:      # line-wrapped record: '\n' / '\r\n' must be skipped
+            w = int(rng.integers(1, 80))
+            s = ("\r\n" if i % 2 else "\n").join(s[j:j + w] for j in range(0, len(s), w)) + "\n"
+        strings.append(s)
+    db_L = 5 * ncol
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    W = _lib.lib().stag_words_per_row(5 * 700)
+    bits = np.zeros((n, W), dtype=np.uint32)
+    n_char, n_al, status = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    _lib.check(_lib.lib().stag_encode_a2m(0, 5 * 700, _lib.ptr(text), _lib.ptr(offs), n, 40.0, _lib.ptr(bits),
+                                          _lib.ptr(n_char), _lib.ptr(n_al), _lib.ptr(status)))
+    dense = tables.unpack_rows(bits, W * 32)
+    for i, s in enumerate(clean):
+        exp, e_char, e_al = oracle_c.encode_a2m(s)
+        assert n_char[i] == e_char and n_al[i] == e_al
+        assert np.array_equal(dense[i, :5 * e_char], exp)
+        assert not dense[i, 5 * e_char:].any()
+        if e_char == 0:
+            assert status[i] == _lib.SEQ_ZERO_COLUMNS
+        elif not oracle_c.passes_filter(e_al, e_char, 40.0):
+            assert status[i] == _lib.SEQ_FILTERED
+        else:
+            assert status[i] == (_lib.SEQ_OK if e_char == 700 else _lib.SEQ_LENGTH_MISMATCH)
+    del db_L
+
+
+@pytest.mark.parametrize("case", gu.load("classify_seq.json"), ids=lambda c: c["name"])
+def test_classify_seq_golden(case):
+    taxonomy, tax_function, classifiers = gu.db_from_json(case)
+    X = np.stack([gu.bits(s) for s in case["seqs"]])
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=case["L"]) as db:
+        res = db.classify_onehot(X)
+        for i, exp in enumerate(case["expected"]):
+            st = int(res.status[i])
+            if "error" in exp:
+                assert st != 0 and gu.ERROR_OF_STATUS[st] in exp["error"], (st, exp["error"])
+                with pytest.raises(Exception) as ei:
+                    raise_for_status(res.status[i:i + 1])
+                assert any(c.__name__ in exp["error"] for c in type(ei.value).__mro__[:-2])
+            else:
+                assert st == 0
+                gu.rows_match(db.result_row(res, i, "seq%d" % i), exp["row"], rtol=RTOL)
+
+
+def test_sklearn_predict_proba_parity_on_gpu():
+    g = gu.load("sklearn_parity.json")
+    row = np.array([float(v) for v in g["row"]])
+    other = row.copy()
+    other[0] -= 100.0       # sibling that never wins: the winner's probability is the sklearn model's
+    taxonomy = {"tree_root": ["yes", "other"], "yes": [], "other": []}
+    X = np.stack([gu.bits(s) for s in g["X"]])
+    with Database.from_dicts(taxonomy, {"0": np.array([0.0, 1.0])}, {"yes": row, "other": other}) as db:
+        res = db.classify_onehot(X)
+    assert (res.status == 0).all() and (res.path_node[:, 0] == 1).all()
+    p_sk = np.array([float(v) for v in g["predict_proba"]])
+    np.testing.assert_allclose(res.path_prob[:, 0], p_sk, rtol=RTOL, atol=0)
+
+
+def random_db(rng, ncol, fanouts, density, scale=1.0):
+    L = 5 * ncol
+    taxonomy, classifiers = {"tree_root": []}, {}
+    frontier, nid = ["tree_root"], 0
+    for choices in fanouts:
+        nxt = []
+        for parent in frontier:
+            k = int(rng.choice(choices))
+            kids = []
+            for _ in range(k):
+                nid += 1
+                kids.append("n%d" % nid)
+            taxonomy[parent] = kids
+            for kid in kids:
+                taxonomy[kid] = []
+                if k == 1:
+                    classifiers[kid] = "no_negative_examples"
+                else:
+                    w = rng.normal(0, scale, size=1 + L) * (rng.random(1 + L) < density)
+                    w[0] = rng.normal(0, 1)
+                    classifiers[kid] = w
+            nxt.extend(kids)
+        frontier = nxt
+    D = len(fanouts)
+    tax_function = {str(l): rng.normal(0, 1, size=1 + D) for l in range(-1, D)}
+    return taxonomy, tax_function, classifiers
+
+
+def compare_with_oracle(db, odb, res, out, X, classifiers):
+    """Exact on ids/counts/status; RTOL on probabilities; lineage equal unless the margin is tiny."""
+    n = res.n
+    assert np.array_equal(res.status, out["status"])
+    assert np.array_equal(res.n_aligned, out["n_aligned"])
+    n_diverged = 0
+    for i in range(n):
+        if res.status[i] != 0:
+            continue
+        g = [db.names[j] for j in res.path_node[i, :res.path_len[i]]]
+        e = [odb.names[j] for j in out["path_node"][i, :out["path_len"][i]]]
+        if g != e:      # accept only a genuine near-tie at the first differing level
+            d = next(k for k in range(min(len(g), len(e))) if g[k] != e[k])
+            pg = float(oracle_np.run_logistic_prediction(X[i], classifiers[g[d]]))
+            pe = float(oracle_np.run_logistic_prediction(X[i], classifiers[e[d]]))
+            assert abs(pg - pe) <= RTOL * max(pg, pe), (i, g, e, pg, pe)
+            n_diverged += 1
+            continue
+        m = len(g)
+        np.testing.assert_allclose(res.path_prob[i, :m], out["path_prob"][i, :m], rtol=RTOL, atol=0)
+        lead_o = 0
+        while lead_o < m and (out["single_mask"][i] >> lead_o) & 1:
+            lead_o += 1
+        assert res.n_lead_single[i] == lead_o
+        np.testing.assert_allclose(res.level_prob[i], out["level_prob"][i], rtol=RTOL, atol=0)
+        if res.selected[i] != out["selected"][i]:
+            lp = out["level_prob"][i]
+            a, b = lp[res.selected[i]], lp[out["selected"][i]]
+            assert abs(a - b) <= RTOL * max(a, b)
+    assert n_diverged <= max(1, n // 1000)
+
+
+@pytest.mark.parametrize("ncol,fanouts,density,n,kind", [
+    (29, [[4], [1, 2, 3], [0, 1, 2]], 0.3, 50, "onehot"),                 # C1 shape: L=145, tiny batch
+    (400, [[3, 5], [1, 2, 6], [1, 3, 9], [2, 3]], 0.05, 3000, "onehot"),   # fan-out > CB, groups > 64 and < 64
+    (1500, [[6], [2, 7], [1, 4]], 0.02, 700, "window"),                    # C2 row width, gap-padded reads
+    (3200, [[5], [2, 3]], 0.01, 300, "zerofill"),                          # L=16000: 3 LDS chunks per row
+    (64, [[11], [1, 17]], 0.5, 2000, "anybits"),                           # dense rows, wide fan-out, -s style bits
+])
+def test_classify_random_vs_oracle(ncol, fanouts, density, n, kind):
+    rng = np.random.default_rng(ncol * 7 + n)
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, fanouts, density)
+    X = np.zeros((n, L), dtype=bool)
+    sym = rng.integers(0, 5, size=(n, ncol))
+    if kind == "anybits":
+        X = rng.random((n, L)) < 0.2
+    else:
+        if kind == "window":        # amplicon-like: '-' outside a 253-column window
+            start = rng.integers(0, ncol - 253, size=n)
+            cols = np.arange(ncol)[None, :]
+            inside = (cols >= start[:, None]) & (cols < start[:, None] + 253)
+            sym = np.where(inside, rng.integers(1, 5, size=(n, ncol)), 0)
+        X[np.arange(n)[:, None], 5 * np.arange(ncol)[None, :] + sym] = True
+        if kind == "zerofill":
+            X[:, (5 * np.arange(ncol)[:, None] + np.arange(5)[None, :])[rng.random(ncol) < 0.3].ravel()] = False
+    odb = oracle_c.DenseDB(taxonomy, tax_function, classifiers, L)
+    out = odb.classify(X)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        assert db.max_depth == odb.max_depth
+        res = db.classify_onehot(X)
+        compare_with_oracle(db, odb, res, out, X, classifiers)
+        # same batch again on the same handle, smaller: workspace reuse must not leak state
+        res2 = db.classify_onehot(X[: n // 3])
+        assert np.array_equal(res2.path_node, res.path_node[: n // 3])
+        assert np.array_equal(res2.path_prob, res.path_prob[: n // 3])
+
+
+def test_classify_a2m_fused_vs_oracle():
+    """text -> encode -> walk on the GPU against oracle encode + oracle classify, with inserts,
+    a min_perc_state filter, an all-insert record and a wrong-length record."""
+    rng = np.random.default_rng(77)
+    ncol = 120
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[4], [2, 3], [1, 2]], 0.1)
+    strings = []
+    for i in range(400):
+        cols = rng.choice(list("ACGT-N"), size=ncol, p=[0.2, 0.2, 0.2, 0.2, 0.15, 0.05])
+        if i % 5 == 0:
+            cols[: int(rng.integers(20, ncol))] = "-"
+        s = list(cols)
+        for _ in range(int(rng.integers(0, 4))):
+            s.insert(int(rng.integers(0, len(s) + 1)), rng.choice(list("acgt")))
+        strings.append("".join(s))
+    strings[7] = "acgtacgt"                 # ZeroDivisionError in the reference
+    strings[11] = strings[11][:-3]          # wrong number of columns
+    min_perc = 55.0
+    odb = oracle_c.DenseDB(taxonomy, tax_function, classifiers, L)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        res = db.classify_a2m(strings, min_perc_state=min_perc, want_bits=True)
+        keep, X = [], []
+        for i, s in enumerate(strings):
+            bits, n_char, n_al = oracle_c.encode_a2m(s)
+            assert res.n_char[i] == n_char
+            if n_char == 0:
+                assert res.status[i] == _lib.SEQ_ZERO_COLUMNS
+            elif not oracle_c.passes_filter(n_al, n_char, min_perc):
+                assert res.status[i] == _lib.SEQ_FILTERED
+            elif 5 * n_char != L:
+                assert res.status[i] == _lib.SEQ_LENGTH_MISMATCH
+            else:
+                keep.append(i)
+                X.append(bits)
+                assert np.array_equal(tables.unpack_rows(res.bits[i:i + 1], L)[0], bits)
+        assert len(keep) > 100 and (res.status != 0).sum() > 20
+        X = np.stack(X)
+        out = odb.classify(X)
+        sub = db.classify_onehot(X)
+        compare_with_oracle(db, odb, sub, out, X, classifiers)
+        keep = np.asarray(keep)
+        assert np.array_equal(res.path_node[keep], sub.path_node)
+        assert np.array_equal(res.path_prob[keep], sub.path_prob)
+        assert np.array_equal(res.selected[keep], sub.selected)
+        assert np.array_equal(res.n_aligned[keep], sub.n_aligned)
+        with pytest.raises(ZeroDivisionError):
+            raise_for_status(res.status)
+
+
+def test_tsv_rows_match_reference_text():
+    g = gu.load("tsv.json")
+    taxonomy, tax_function, classifiers = gu.db_from_json(g["db"])
+    ids, X = zip(*(oracle_np.parse_onehot_line(l) for l in g["ali_lines"]))
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=g["L"]) as db:
+        res = db.classify_onehot(np.stack(X))
+        short = db.result_rows(res, ids, long_out=False)
+        assert short == g["runs"]["internal"]["return_rows"]
+        long_rows = db.result_rows(res, ids, long_out=True)
+        exp = [l.split("\t") for l in g["runs"]["long"]["file"].splitlines()[1:]]
+        for got, e in zip(long_rows, exp):
+            got = list(got)
+            got[3] = str(got[3])
+            gu.rows_match(got, e, rtol=RTOL)
+
+
+def test_empty_batch_and_bad_arguments():
+    taxonomy = {"tree_root": ["a", "b"], "a": [], "b": []}
+    cls = {"a": np.ones(11), "b": -np.ones(11)}
+    with Database.from_dicts(taxonomy, {"0": np.array([0.0, 1.0])}, cls) as db:
+        res = db.classify_onehot(np.zeros((0, 10), dtype=bool))
+        assert res.n == 0
+        res = db.classify_a2m([])
+        assert res.n == 0
+        with pytest.raises(ValueError):
+            db.classify_bits(np.zeros((3, 1), dtype=np.uint32))
+    bad = tables.pack_db(taxonomy, {"0": np.array([0.0, 1.0])}, cls)
+    bad.child_first = np.array([1, 2, 3, 3], dtype=np.int32)
+    with pytest.raises(_lib.StagError):
+        Database(bad)
