@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the post-alignment classification path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): a synthetic 16S amplicon stagDB (ncol 1500 -> L 7500,
+7 ranks, ~20k nodes, 2 % non-zero fp64 coefficients per row) and 1M synthetic 250-bp V4 reads,
+pre-aligned (A2M text: '-' outside a 253-column window, 0-3 lowercase inserts).  One step = one
+pass of aligned text -> one-hot rows -> level-synchronous walk -> rank cut over the whole
+batch, inputs and outputs resident in HBM.  N GPUs: one process per GPU, each classifies its
+own 1M-read shard against its own replica of the tables (weak scaling, no collective on the
+data path; torch.distributed is used only for the barrier and the max-over-ranks time).
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for how roofline and cpu_baseline
+are defined).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
+    ap.add_argument("--db-scale", type=float, default=1.0, help="scales the node count of the synthetic tree")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=300, help="reads timed through the NumPy port")
+    ap.add_argument("--check", type=int, default=2000, help="reads compared with the C oracle after the run")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import bench_workload as bw
+    from stag_amd import _lib
+    from stag_amd.engine import Database
+
+    wl = bw.config_16s(seed=2, scale=args.db_scale)
+    t = wl.tables
+    n = args.reads
+    text, offs, _ = bw.make_reads(wl, seed=1000 + rank, n=n)
+    db = Database(t, device=local)
+    D, K, W = db.max_depth, db.n_keys, db.words_per_row
+    dev = torch.device("cuda", local)
+    d_text = torch.from_numpy(text).to(dev)
+    d_offs = torch.from_numpy(offs).to(dev)
+    out = {
+        "path_node": torch.empty((n, D), dtype=torch.int32, device=dev),
+        "path_prob": torch.empty((n, D), dtype=torch.float64, device=dev),
+        "path_len": torch.empty(n, dtype=torch.int32, device=dev),
+        "n_lead_single": torch.empty(n, dtype=torch.int32, device=dev),
+        "level_prob": torch.empty((n, K), dtype=torch.float64, device=dev),
+        "selected": torch.empty(n, dtype=torch.int32, device=dev),
+        "n_aligned": torch.empty(n, dtype=torch.int32, device=dev),
+        "status": torch.empty(n, dtype=torch.int32, device=dev),
+    }
+    res = _lib.Results()
+    for f, _ in _lib.Results._fields_:
+        setattr(res, f, out[f].data_ptr())
+    db.reserve(n, len(text))
+    stream = torch.cuda.current_stream(dev)
+    lib = _lib.lib()
+
+    def step():
+        _lib.check(lib.stag_classify_a2m_dev(db.handle, d_text.data_ptr(), len(text), d_offs.data_ptr(), n, 0.0,
+                                             ctypes.byref(res), stream.cuda_stream))
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # per-kernel device time (HIP events on the launch stream, recorded inside the library)
+    prof_steps = max(1, min(args.steps, 5))
+    db.profile_enable(True)
+    for _ in range(prof_steps):
+        step()
+    prof = db.profile_read()
+    db.profile_enable(False)
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    n_ok = int((out["status"] == 0).sum().item())
+    # ---- algorithmic bytes: B_seq = A + ncol + R
+    A = float(offs[-1]) / n
+    ncol = wl.ncol
+    R = D * 12 + K * 8 + 12
+    b_seq = A + ncol + R
+    walk_ms, walk_launches = prof["walk_level"]
+    total_ms = sum(v[0] for v in prof.values())
+    walk_avg_ms = walk_ms / max(walk_launches, 1)
+    # the walk's share of B_seq (rows read once + results), spread over the D level launches of a step
+    walk_bytes_per_launch = n * (ncol + R) / D
+    achieved = walk_bytes_per_launch / (walk_avg_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": "k_walk_level", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "avg_launch_ms": round(walk_avg_ms, 4), "launches_per_step": walk_launches // prof_steps,
+        "algorithmic_bytes_per_launch": int(walk_bytes_per_launch),
+        "path": {   # whole step priced as one pass: B_seq * n over the device time of ALL its kernels
+            "bytes_per_seq": round(b_seq, 1),
+            "device_ms_per_step": round(total_ms / prof_steps, 4),
+            "achieved": round(b_seq * n / (total_ms / prof_steps * 1e-3) / 1e9, 2),
+            "frac": round(b_seq * n / (total_ms / prof_steps * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        },
+        "kernel_ms_per_step": {k: round(v[0] / prof_steps, 4) for k, v in prof.items()},
+    }
+
+    # ---- parity spot check against the C oracle on the first reads of rank 0's shard
+    parity = None
+    if args.check > 0:
+        from oracle import oracle_c
+        m = min(args.check, n)
+        odb = oracle_c.DenseDB.from_packed(t)
+        X = np.zeros((m, t.n_features), dtype=np.uint8)
+        ok_len = np.zeros(m, dtype=bool)
+        for i in range(m):
+            b, n_char, _ = oracle_c.encode_a2m(bytes(text[offs[i]:offs[i + 1]]).decode("latin-1"))
+            ok_len[i] = 5 * n_char == t.n_features
+            if ok_len[i]:
+                X[i] = b
+        o = odb.classify(X)
+        g_node = out["path_node"][:m].cpu().numpy()
+        g_prob = out["path_prob"][:m].cpu().numpy()
+        g_lp = out["level_prob"][:m].cpu().numpy()
+        same_path = (g_node == o["path_node"]).all(axis=1)
+        rel = np.abs(g_prob - o["path_prob"]) / np.maximum(np.abs(o["path_prob"]), 1e-300)
+        rel_lp = np.abs(g_lp - o["level_prob"]) / np.maximum(np.abs(o["level_prob"]), 1e-300)
+        parity = {"checked": m, "lineage_equal": int(same_path.sum()),
+                  "max_rel_err_node_prob": float(rel[same_path].max()) if same_path.any() else None,
+                  "max_rel_err_level_prob": float(rel_lp[same_path].max()) if same_path.any() else None,
+                  "n_aligned_equal": bool((out["n_aligned"][:m].cpu().numpy() == o["n_aligned"]).all())}
+        del odb, X
+
+    # ---- CPU baseline: the NumPy port (reference cost structure, 1 core) on a bounded sample
+    cpu = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle_np
+        taxonomy = bw.taxonomy_dict(t)
+        tax_function = bw.tax_function_dict(t)
+        classifiers = bw.LazyClassifiers(t)
+        sample = min(args.cpu_sample, n)
+        strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(sample)]
+        for s in strings[:20]:      # materialise the hot rows outside the timed region
+            oracle_np.classify_seq("w", oracle_np.convert_alignment(s)[0], taxonomy, tax_function, classifiers)
+        c0 = time.perf_counter()
+        for i, s in enumerate(strings):
+            x, _ = oracle_np.convert_alignment(s)
+            oracle_np.classify_seq(str(i), x, taxonomy, tax_function, classifiers)
+        cdt = time.perf_counter() - c0
+        cpu = {"value": round(sample / cdt, 2), "unit": "seqs/s", "cores": 1, "kind": "port",
+               "sample": "%d reads of the same batch through oracle/oracle_np.py (per-sequence NumPy, the "
+                         "reference's cost structure; `stag classify -t N` is single-core on this path); "
+                         "host has %d cores" % (sample, os.cpu_count())}
+
+    value = n * world * args.steps / dt
+    print(json.dumps({
+        "metric": "classified seqs/sec post-hmmalign", "value": round(value, 1), "unit": "seqs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "C2: 16S amplicon stagDB, 1M synthetic 250-bp V4 reads pre-aligned, per GPU",
+                   "reads_per_gpu": n, "ncol": ncol, "L": t.n_features, "depth": D, "n_nodes": t.n_nodes,
+                   "nnz_coefficients": t.nnz, "table_bytes": db.table_bytes, "classified_ok": n_ok,
+                   "sharding": "reads split across ranks, tables replicated, no collective"},
+        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+    }))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -119,6 +119,34 @@ class DenseDB:
             frontier = nxt
         self.max_depth = max(depth, 1)
 
+    @classmethod
+    def from_packed(cls, t):
+        """From flat arrays (names, child_first, row_kind, intercept, row_off, row_feat, row_w, keys,
+        tf, n_features) -- used by bench.py where 20k dense rows never exist as a dict."""
+        self = cls.__new__(cls)
+        n = len(t.names)
+        self.names, self.L = list(t.names), int(t.n_features)
+        self.child_off = (np.asarray(t.child_first, dtype=np.int64) - 1).astype(np.int32)
+        self.child_ids = np.arange(1, n, dtype=np.int32)
+        self.row_kind = np.ascontiguousarray(t.row_kind, dtype=np.uint8)
+        self.rows = np.zeros((n, 1 + self.L), dtype=np.float64)
+        self.rows[:, 0] = t.intercept
+        lens = np.diff(t.row_off)
+        self.rows[np.repeat(np.arange(n), lens), 1 + np.asarray(t.row_feat)] = t.row_w
+        self.keys = list(t.keys)
+        self.tf = np.ascontiguousarray(t.tf, dtype=np.float64)
+        self.n_tf = self.tf.shape[1] - 1 if len(self.keys) else 0
+        depth, frontier_lo, frontier_hi = 0, 0, 1
+        while True:
+            lo, hi = self.child_off[frontier_lo] + 1, self.child_off[frontier_hi] + 1
+            if hi == lo:
+                break
+            depth, frontier_lo, frontier_hi = depth + 1, lo, hi
+            if hi >= n:
+                break
+        self.max_depth = max(depth, 1)
+        return self
+
     def classify(self, X):
         """X: bool/uint8 [n, L].  Returns dict of arrays (see stag_oracle.c)."""
         X = np.ascontiguousarray(X, dtype=np.uint8)

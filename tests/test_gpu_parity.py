@@ -287,6 +287,6 @@ def test_empty_batch_and_bad_arguments():
         with pytest.raises(ValueError):
             db.classify_bits(np.zeros((3, 1), dtype=np.uint32))
     bad = tables.pack_db(taxonomy, {"0": np.array([0.0, 1.0])}, cls)
-    bad.child_first = np.array([1, 2, 3, 3], dtype=np.int32)
+    bad.child_first = np.array([1, 3, 2, 3], dtype=np.int32)   # not monotone
     with pytest.raises(_lib.StagError):
         Database(bad)
