@@ -25,6 +25,8 @@ def make_tree(rng, level_sizes):
     for target in level_sizes:
         mean = max(target / parents, 1.0)
         k = rng.geometric(1.0 / mean, size=parents) if mean > 1.0 else np.ones(parents, dtype=np.int64)
+        if parents == 1:
+            k = np.array([target], dtype=np.int64)            # the root's fan-out is not left to one draw
         counts.append(k)
         parents = int(k.sum())
     counts.append(np.zeros(parents, dtype=np.int64))          # the deepest level has no children

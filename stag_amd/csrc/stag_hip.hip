@@ -237,7 +237,8 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
         const int lo = db->level_start[d], hi = db->level_start[d + 1];
         {
             Prof p(db, st, 2);
-            hipLaunchKernelGGL(k_assign, dim3(g256), dim3(256), 0, st, n, db->node.p, db->count.p, db->pos.p);
+            hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_THREADS - 1) / ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, st,
+                               n, lo, hi, db->node.p, db->count.p, db->pos.p);
             hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->node_off.p,
                                db->task_off.p, db->n_tasks.p + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, db->node.p, db->pos.p, db->count.p,

@@ -16,10 +16,10 @@
 namespace stagk {
 
 constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
-constexpr int NW = 4;             // waves per walk workgroup
+constexpr int NW = 8;             // waves per walk workgroup (all share the 64 staged rows)
 constexpr int CHUNK_WORDS = 240;  // packed-row words staged in LDS per pass (7,680 features)
 constexpr int ROW_STRIDE = CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
-constexpr int CB = 4;             // sibling rows scored per pass
+constexpr int CB = 2;             // sibling rows scored per pass
 constexpr int BLOCK_ENTRIES = 4;
 
 struct Entry {      // 16 bytes
@@ -171,14 +171,39 @@ __global__ __launch_bounds__(256) void k_init_walk(int64_t n, int D, const int32
 }
 
 // pos[s] = rank of s among the sequences of its node, count[node] = sequences at that node.
-// One returning atomic per (wave, distinct node) instead of one per sequence.
-__global__ __launch_bounds__(256) void k_assign(int64_t n, const int32_t *__restrict__ node,
-                                                int32_t *__restrict__ count, int32_t *__restrict__ pos) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// A hot node (top levels: every sequence stands on one of a few nodes) would serialise
+// returning atomics on one word (~88 per us), so sequences are first counted per workgroup:
+//  * levels with <= ASSIGN_BINS nodes: LDS histogram over the level's node range, then one
+//    global atomic per (workgroup, non-empty bin);
+//  * wider levels: per-wave grouping by ballot (ALU only), then one atomic per (wave, node).
+constexpr int ASSIGN_BINS = 4096;
+constexpr int ASSIGN_THREADS = 1024;
+
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, int hi,
+                                                           const int32_t *__restrict__ node,
+                                                           int32_t *__restrict__ count, int32_t *__restrict__ pos) {
+    __shared__ int s_cnt[ASSIGN_BINS];
+    const int64_t s = (int64_t)blockIdx.x * ASSIGN_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    const int nd = s < n ? node[s] : -1;
+    int nd = s < n ? node[s] : -1;
+    if (nd < lo || nd >= hi) nd = -1;
+    const int nbins = hi - lo;
+    if (nbins <= ASSIGN_BINS) {
+        for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) s_cnt[b] = 0;
+        __syncthreads();
+        int rank = 0;
+        if (nd >= 0) rank = atomicAdd(&s_cnt[nd - lo], 1);
+        __syncthreads();
+        for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) {
+            const int c = s_cnt[b];
+            s_cnt[b] = c ? atomicAdd(&count[lo + b], c) : 0;
+        }
+        __syncthreads();
+        if (nd >= 0) pos[s] = s_cnt[nd - lo] + rank;
+        return;
+    }
     bool todo = nd >= 0;
-    int my_pos = 0;
+    int rank = 0, cnt = 0, leader_lane = lane;
     for (;;) {
         const unsigned long long pending = __ballot(todo);
         if (!pending) break;
@@ -186,15 +211,17 @@ __global__ __launch_bounds__(256) void k_assign(int64_t n, const int32_t *__rest
         const int n0 = __shfl(nd, leader);
         const bool mine = todo && nd == n0;
         const unsigned long long same = __ballot(mine);
-        int base = 0;
-        if (lane == leader) base = atomicAdd(&count[n0], __popcll(same));
-        base = __shfl(base, leader);
         if (mine) {
-            my_pos = base + __popcll(same & ((1ull << lane) - 1ull));
+            rank = __popcll(same & ((1ull << lane) - 1ull));
+            cnt = __popcll(same);
+            leader_lane = leader;
             todo = false;
         }
     }
-    if (nd >= 0) pos[s] = my_pos;
+    int base = 0;
+    if (nd >= 0 && lane == leader_lane) base = atomicAdd(&count[nd], cnt);
+    base = __shfl(base, leader_lane);
+    if (nd >= 0) pos[s] = base + rank;
 }
 
 // One workgroup: exclusive scans over the nodes [lo, hi) of one level.
@@ -326,8 +353,8 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         for (int ch = 0; ch < a.nchunks; ++ch) {
             const int cw = min(CHUNK_WORDS, a.W - ch * CHUNK_WORDS);
             const int q = cw >> 2;
+            if (a.nchunks > 1 || cb == 0) {  // a one-chunk row is staged once for all sibling passes
             __syncthreads();  // everyone is done reading the previous chunk
-#pragma unroll 4
             for (int r = wave; r < TILE; r += NW) {
                 const int s = __shfl(seq, r);  // wave-uniform
                 for (int j = lane; j < q; j += 64) {
@@ -339,6 +366,7 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
                 }
             }
             __syncthreads();
+            }
             for (int ci = 0; ci < kb; ++ci) {
                 const uint32_t seg = (uint32_t)(c0 + cb + ci) * a.nchunks + ch;
                 const uint32_t b0 = blk_off[seg], b1 = blk_off[seg + 1];
