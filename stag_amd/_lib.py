@@ -6,7 +6,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libstag_hip.so")
+# STAG_HIP_LIB selects another build of the same library (kernel ablation variants for profiling)
+LIB_PATH = os.environ.get("STAG_HIP_LIB") or os.path.join(_HERE, "lib", "libstag_hip.so")
 
 STAG_OK = 0
 SEQ_OK, SEQ_MISSING_CLASSIFIER, SEQ_STRING_CLASSIFIER, SEQ_RANKCUT_SHAPE, SEQ_EMPTY_PATH, \

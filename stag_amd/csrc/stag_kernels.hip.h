@@ -5,8 +5,8 @@
 //                                W = ceil(L/32) rounded up to 4 words (16-byte rows)
 //   coefficient blocks           each child row's NON-ZERO coefficients, sorted by feature, cut
 //                                at CHUNK_WORDS-word boundaries and padded per (row, chunk) to
-//                                blocks of 4 entries {byte offset, bit, fp64 w} = 64 B, so that one
-//                                s_load_dwordx16 fetches a block into SGPRs for a whole wave
+//                                blocks of 8 entries {byte offset, bit, fp64 w} = 128 B, so that two
+//                                s_load_dwordx16 fetch a block into SGPRs for a whole wave
 //   grouping      node[n], pos[n], order[n], tasks[]: sequences sorted by current tree node,
 //                                cut into tasks of <= 64 sequences of one node
 #pragma once
@@ -19,8 +19,7 @@ constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
 constexpr int NW = 8;             // waves per walk workgroup (all share the 64 staged rows)
 constexpr int CHUNK_WORDS = 240;  // packed-row words staged in LDS per pass (7,680 features)
 constexpr int ROW_STRIDE = CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
-constexpr int CB = 2;             // sibling rows scored per pass
-constexpr int BLOCK_ENTRIES = 4;
+constexpr int BLOCK_ENTRIES = 8;   // entries per scalar fetch (2 x s_load_dwordx16)
 
 struct Entry {      // 16 bytes
     uint32_t off;   // byte offset of the feature's word inside the staged chunk of a row
@@ -313,8 +312,8 @@ __device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 
 
 __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
     __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
-    __shared__ double s_z[NW][CB][TILE];
-    __shared__ double s_p[CB][TILE];
+    __shared__ double s_z[NW][TILE];
+    __shared__ int s_c[NW][TILE];
 
     if ((int)blockIdx.x >= *as_const(a.n_tasks)) return;
     const i32x4 tkv = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];
@@ -344,61 +343,100 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         return;
     }
 
+    // Siblings are scored NW at a time ("pass"), one per wave; a pass with fewer than NW
+    // siblings splits each sibling's blocks over P = NW / siblings waves.  Which blocks a wave
+    // sums depends only on (sibling's block index, P), so identical rows give identical sums
+    // and exact ties resolve to the first stored child like the reference's strict '>'.
     double best_p = -1.0;
     int best_c = -1;
     const char *my_row = reinterpret_cast<const char *>(s_rows + lane * ROW_STRIDE);
 
-    for (int cb = 0; cb < k; cb += CB) {
-        const int kb = min(CB, k - cb);
+    for (int pass0 = 0; pass0 < k; pass0 += NW) {
+        const int kk = min(NW, k - pass0);
+        const int P = NW / kk;
+        const int ci = wave / P, part = wave - ci * P;
+        const bool active = ci < kk;
+        const int c = c0 + pass0 + ci;
+        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
         for (int ch = 0; ch < a.nchunks; ++ch) {
-            const int cw = min(CHUNK_WORDS, a.W - ch * CHUNK_WORDS);
-            const int q = cw >> 2;
-            if (a.nchunks > 1 || cb == 0) {  // a one-chunk row is staged once for all sibling passes
-            __syncthreads();  // everyone is done reading the previous chunk
-            for (int r = wave; r < TILE; r += NW) {
-                const int s = __shfl(seq, r);  // wave-uniform
-                for (int j = lane; j < q; j += 64) {
-                    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                    if (s >= 0)
-                        v = *reinterpret_cast<const uint4 *>(a.bits + (size_t)s * a.W + ch * CHUNK_WORDS + 4 * j);
-                    uint32_t *d = s_rows + r * ROW_STRIDE + 4 * j;
-                    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if (a.nchunks > 1 || pass0 == 0) {  // a one-chunk row is staged once for all passes
+                const int cw = min(CHUNK_WORDS, a.W - ch * CHUNK_WORDS);
+                __syncthreads();  // everyone is done reading the previous chunk
+#ifndef STAG_ABLATE_NO_STAGE
+                // One row per wave and step, lanes over consecutive words: 256-byte coalesced
+                // loads, and LDS stores that hit 32 different banks (a uint4 per lane would put
+                // every fourth dword of a row on the same bank: 4-way conflicts on each store).
+                static_assert(CHUNK_WORDS <= 4 * 64, "staging loop covers a chunk in four 64-word steps");
+#pragma unroll
+                for (int r0 = 0; r0 < TILE; r0 += 4 * NW) {
+                    uint32_t v[4][4];
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        const int r = r0 + rr * NW + wave;
+                        const int s = __shfl(seq, r);  // wave-uniform
+                        const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + ch * CHUNK_WORDS;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int w = lane + 64 * i;
+                            v[rr][i] = (s >= 0 && w < cw) ? src[w] : 0u;
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) {
+                        uint32_t *d = s_rows + (r0 + rr * NW + wave) * ROW_STRIDE;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            if (lane + 64 * i < CHUNK_WORDS) d[lane + 64 * i] = v[rr][i];
+                    }
                 }
+#endif
+                __syncthreads();
             }
-            __syncthreads();
-            }
-            for (int ci = 0; ci < kb; ++ci) {
-                const uint32_t seg = (uint32_t)(c0 + cb + ci) * a.nchunks + ch;
+#ifndef STAG_ABLATE_NO_ENTRIES
+            if (active) {
+                const uint32_t seg = (uint32_t)c * a.nchunks + ch;
                 const uint32_t b0 = blk_off[seg], b1 = blk_off[seg + 1];
-                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-                for (uint32_t b = b0 + wave; b < b1; b += NW) {
+                for (uint32_t b = b0 + part; b < b1; b += P) {
                     const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
-                    const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                    const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5], e6 = e[6], e7 = e[7];
                     z0 += masked_weight(my_row, e0);
                     z1 += masked_weight(my_row, e1);
                     z2 += masked_weight(my_row, e2);
                     z3 += masked_weight(my_row, e3);
+                    z0 += masked_weight(my_row, e4);
+                    z1 += masked_weight(my_row, e5);
+                    z2 += masked_weight(my_row, e6);
+                    z3 += masked_weight(my_row, e7);
                 }
-                const double z = (z0 + z1) + (z2 + z3);
-                if (ch == 0) s_z[wave][ci][lane] = z; else s_z[wave][ci][lane] += z;
             }
+#else
+            if (active) z0 += (double)my_row[ch];
+#endif
         }
-        __syncthreads();
-        for (int ci = wave; ci < kb; ci += NW) {
-            double z = 0.0;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) z += s_z[w][ci][lane];
-            s_p[ci][lane] = sigmoid(z + as_const(a.intercept)[c0 + cb + ci]);
-        }
-        __syncthreads();
-        if (wave == 0) {
-            for (int ci = 0; ci < kb; ++ci) {
-                const double p = s_p[ci][lane];
-                if (p > best_p) { best_p = p; best_c = c0 + cb + ci; }  // strict '>' in stored order
+        double z = (z0 + z1) + (z2 + z3);
+        if (P > 1) {  // workgroup-uniform: combine the P partial sums of each sibling in a fixed order
+            s_z[wave][lane] = z;
+            __syncthreads();
+            if (active && part == 0) {
+                z = 0.0;
+                for (int j = 0; j < P; ++j) z += s_z[wave + j][lane];
             }
+            __syncthreads();
+        }
+        if (active && part == 0) {
+            const double p = sigmoid(z + as_const(a.intercept)[c]);
+            if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
         }
     }
+    s_z[wave][lane] = best_p;
+    s_c[wave][lane] = best_c;
+    __syncthreads();
     if (wave == 0 && seq >= 0) {
+        for (int w = 1; w < NW; ++w) {  // first maximum in stored order = largest p, then smallest id
+            const double p = s_z[w][lane];
+            const int cc = s_c[w][lane];
+            if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
+        }
         if (best_c >= 0) {
             a.path_node[(size_t)seq * a.D + a.depth] = best_c;
             a.path_prob[(size_t)seq * a.D + a.depth] = best_p;
