@@ -1,0 +1,93 @@
+"""Alignment stream driver: mirror of stag/align.py:98-180 (zellerlab/stag 0.8.2) feeding the GPU.
+
+hmmalign / cmalign and esl-reformat stay the reference's external CPU step.  What changes is
+what happens to their output: instead of one-hot encoding every record in a Python loop
+(align.py:37-58), records are collected into batches of aligned text that the HIP encode
+kernel converts and filters on the GPU.  Protein databases back-translate each record to a
+codon alignment first (align.py:63-94) through the C ABI (stag_backtranslate).
+"""
+import ctypes
+import shlex
+import subprocess
+import sys
+
+from . import _lib
+from .helpers import is_tool, read_fasta
+
+BATCH_RECORDS = 1 << 16      # records handed to the GPU at a time
+
+
+def protein2gene_alignment(gene_id, protein_alignment, gene_sequence, check_length=True):
+    """align.py:63-94 via libstag_hip's host entry point.  None when the lengths do not fit."""
+    p = protein_alignment.encode("latin-1", "replace")
+    g = gene_sequence.encode("latin-1", "replace")
+    out = ctypes.create_string_buffer(3 * len(p) + 4)
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.lib().stag_backtranslate(p, len(p), g, len(g), int(bool(check_length)), out, ctypes.byref(n)))
+    if n.value < 0:
+        sys.stderr.write("Error, length of genes/alignment is not correct")
+        n_res = len(p) - p.count(b"-")
+        sys.stderr.write(" (protein: " + str(n_res * 3) + ", gene: " + str(len(g)) + ")\n")
+        sys.stderr.write(" ID: " + gene_id + "\n")
+        return None
+    return out.raw[:n.value].decode("latin-1")
+
+
+def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose):
+    """The part of align_generator (align.py:98-175) before the one-hot conversion: yields
+    (id, nucleotide-aligned string) and checks the tools' exit codes once the stream drains."""
+    if use_cmalign and not is_tool("cmalign"):
+        raise ValueError("[E::align] Error: cmalign is not in the path. Please install Infernal.")
+    elif not is_tool("hmmalign"):
+        raise ValueError("[E::align] Error: hmmalign is not in the path. Please install HMMER3.")
+    if not is_tool("esl-reformat"):
+        raise ValueError("[E::align] Error: esl-reformat is not in the path. Please install Easel.")
+
+    aligner = f"cmalign --cpu {n_threads}" if use_cmalign else "hmmalign"
+    seq_input = protein_file if protein_file else seq_file
+    align_cmd = f"{aligner} {hmm_file} {seq_input}"
+    if verbose > 4:
+        print(f"Command used to align the sequences: {align_cmd}", file=sys.stderr)
+    align_proc = subprocess.Popen(shlex.split(align_cmd), stdout=subprocess.PIPE)
+    parse_proc = subprocess.Popen(shlex.split("esl-reformat a2m -"), stdin=align_proc.stdout, stdout=subprocess.PIPE)
+
+    if protein_file:
+        gene_fh = open(seq_file)
+        stream = zip(read_fasta(parse_proc.stdout, head_start=1), read_fasta(gene_fh, is_binary=False, head_start=1))
+    else:
+        gene_fh = None
+        stream = read_fasta(parse_proc.stdout, head_start=1)
+    try:
+        for item in stream:
+            if protein_file:
+                (pid, pseq), (gid, gseq) = item
+                if pid != gid:
+                    sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(pid, gid))
+                    sys.exit(1)
+                gseq = protein2gene_alignment(gid, pseq, gseq, check_length=True)
+                if gseq is None:   # the reference goes on and fails in convert_alignment(None)
+                    raise TypeError("'NoneType' object is not iterable")
+            else:
+                gid, gseq = item
+            yield gid, gseq
+    finally:
+        if gene_fh:
+            gene_fh.close()
+    align_proc.stdout.close()
+    if align_proc.wait():
+        raise ValueError("[E::align] Error. hmmalign/cmalign failed.")
+    parse_proc.stdout.close()
+    if parse_proc.wait():
+        raise ValueError("[E::align] Error. esl-reformat failed.")
+
+
+def batched(records, size=BATCH_RECORDS):
+    ids, seqs = [], []
+    for gid, s in records:
+        ids.append(gid)
+        seqs.append(s)
+        if len(ids) >= size:
+            yield ids, seqs
+            ids, seqs = [], []
+    if ids:
+        yield ids, seqs

@@ -1,0 +1,185 @@
+"""``classify``: drop-in for stag/classify.py:131-207 (zellerlab/stag 0.8.2) on MI355X.
+
+Same signature, same files, same return value ``(alignment_length, rows)``.  What differs is
+where the work happens: the per-sequence Python loop of the reference (classify.py:155-158 ->
+classify_seq) becomes batches through the HIP kernels (stag_amd.engine.Database); only text
+parsing and text formatting stay on the host.  ``threads`` is accepted and, as in the
+reference (classify.py:94), only reaches ``cmalign --cpu``.
+"""
+import contextlib
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+from . import __version__ as tool_version
+from . import _lib, align, parallel
+from .databases import load_db
+from .engine import Database, raise_for_status
+from .tables import pack_db, unpack_rows
+
+OUT_HEADER = ["sequence", "taxonomy", "full_taxonomy", "selected_level",
+              "prob_from_classifiers", "prob_per_level", "n_aligned_characters"]
+READER_BATCH = 1 << 14
+
+
+def parse_onehot_line(ali_line):
+    """One line of a -s file (classify.py:19-20): id, bool[L]; any non-zero integer is True."""
+    gene_id, *fields = ali_line.rstrip().split("\t")
+    n = len(fields)
+    body = ali_line.rstrip()[len(gene_id) + 1:] if n else ""
+    if len(body) == 2 * n - 1:                       # every field is a single character: no int() per field
+        raw = np.frombuffer(body.encode("latin-1"), dtype=np.uint8)[0::2]
+        if ((raw == 48) | (raw == 49)).all():
+            return gene_id, raw == 49
+    return gene_id, np.array(list(map(int, fields)), dtype=bool)
+
+
+def alignment_reader(aligned_sequences):
+    """classify.py:16-20."""
+    with open(aligned_sequences, "r") as align_in:
+        for ali_line in align_in:
+            yield parse_onehot_line(ali_line)
+
+
+def _classify_prealigned(db, aligned_sequences, tagged, state):
+    """-s path: rows arrive already one-hot encoded (any bit pattern).  Under torchrun the
+    batches of the stream are dealt round-robin to the ranks (parallel.owner_of_batch)."""
+    world, rank = parallel.world_rank()
+    ids, X = [], []
+    batch = [0]
+
+    def flush():
+        b = batch[0]
+        batch[0] += 1
+        if not ids or parallel.owner_of_batch(b, world) != rank:
+            ids.clear()
+            X.clear()
+            return
+        L = db.n_features
+        good = np.array([len(x) == L for x in X])
+        M = np.zeros((len(X), L), dtype=bool)
+        for i, x in enumerate(X):
+            if good[i]:
+                M[i] = x
+        res = db.classify_bits(_pack(M, db), np.where(good, _lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH).astype(np.int32))
+        tagged.append((b, db.result_rows(res, ids, long_out=True)))
+        ids.clear()
+        X.clear()
+
+    for gene_id, ali in alignment_reader(aligned_sequences):
+        if not state["alignment_length"]:
+            state["alignment_length"] = len(ali)
+        ids.append(gene_id)
+        X.append(ali)
+        if len(ids) >= READER_BATCH:
+            flush()
+    flush()
+
+
+def _pack(M, db):
+    from .tables import pack_bool_rows
+    return pack_bool_rows(M, db.words_per_row)
+
+
+def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, threads=1, output=None,
+             long_out=False, current_tool_version=tool_version,
+             aligned_sequences=None, save_ali_to_file=None, min_perc_state=0, internal_call=False, device=None):
+    t0 = time.time()
+    loaded = load_db(database, protein_fasta_input=protein_fasta_input, aligned_sequences=aligned_sequences)
+    hmm_file_path, use_cmalign, taxonomy, tax_function, classifiers, db_tool_version = loaded
+    tables = pack_db(taxonomy, tax_function, classifiers)
+    del classifiers
+    db = Database(tables, device=parallel.local_device() if device is None else device)
+    world, rank = parallel.world_rank()
+    time_after_loading = time.time()
+    if verbose > 2:
+        sys.stderr.write("Load database: " + str("{0:.2f}".format(time_after_loading - t0)) + " sec\n")
+
+    state = {"alignment_length": None}
+    tagged = []          # (batch index, rows) of the batches this rank classified
+    n_pass = n_not_pass = 0
+    error = None
+    try:
+        if aligned_sequences:
+            _classify_prealigned(db, aligned_sequences, tagged, state)
+        else:
+            records = align.aligned_records(fasta_input, protein_fasta_input, hmm_file_path, use_cmalign,
+                                            threads, verbose)
+            alignment_out = open(save_ali_to_file, "w") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
+            with alignment_out:
+                for b, (ids, seqs) in enumerate(align.batched(records)):
+                    mine = parallel.owner_of_batch(b, world) == rank
+                    if not mine and not (save_ali_to_file and rank == 0) and state["alignment_length"]:
+                        continue
+                    res = db.classify_a2m(seqs, min_perc_state=min_perc_state,
+                                          want_bits=bool(save_ali_to_file) and rank == 0)
+                    raise_for_status(res.status, ids)
+                    passed = np.flatnonzero(res.status == _lib.SEQ_OK)
+                    n_pass += len(passed)
+                    n_not_pass += len(ids) - len(passed)
+                    if len(passed) and not state["alignment_length"]:
+                        state["alignment_length"] = 5 * int(res.n_char[passed[0]])
+                    if mine:
+                        tagged.append((b, db.result_rows(res, ids, long_out=True)))
+                    if save_ali_to_file and rank == 0 and len(passed):
+                        dense = unpack_rows(res.bits[passed], db.n_features)
+                        for i, x in zip(passed, dense):       # classify.py:160-162
+                            print(ids[i], "\t".join(np.where(x, "1", "0")), sep="\t", file=alignment_out)
+            if verbose > 3 and world == 1:
+                print(f" Number of sequences that pass the filter: {n_pass}", file=sys.stderr)
+                print(f" Number of sequences that do not pass the filter: {n_not_pass}", file=sys.stderr)
+    except Exception as e:       # re-raised on every rank by gather_in_order
+        error = e
+    finally:
+        db.close()
+    if error is not None:
+        os.remove(hmm_file_path)
+    list_to_print = parallel.gather_in_order(tagged, error)
+    if rank != 0:
+        os.remove(hmm_file_path)
+        return state["alignment_length"], []
+
+    if verbose > 2:
+        sys.stderr.write("Classify sequences: " + str("{0:.2f}".format(time.time() - time_after_loading)) + " sec\n")
+
+    os.remove(hmm_file_path)       # classify.py:169
+
+    # ---- output, classify.py:172-207
+    if output:
+        outfile = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        os.chmod(outfile.name, 0o644)
+    else:
+        outfile = sys.stdout
+    out_header = OUT_HEADER
+    if not long_out or internal_call:
+        out_header = out_header[:2]
+        list_to_print = [item[:2] for item in list_to_print]
+    if not internal_call:
+        try:
+            print(*out_header, sep="\t", file=outfile)
+            for line in list_to_print:
+                print(*line, sep="\t", file=outfile)
+            if output:
+                try:
+                    outfile.flush()
+                    os.fsync(outfile.fileno())
+                except Exception:
+                    sys.stderr.write("[E::main] Error: failed to save the result\n")
+                    sys.exit(1)
+        finally:
+            if output:
+                outfile.close()      # the reference also closes sys.stdout here; we leave it open
+            else:
+                outfile.flush()
+        if output:
+            try:
+                shutil.move(outfile.name, output)
+            except Exception:
+                sys.stderr.write("[E::main] Error: failed to save the profile\n")
+                sys.stderr.write("[E::main] you can find the file here:\n" + outfile.name + "\n")
+                sys.exit(1)
+    return state["alignment_length"], list_to_print

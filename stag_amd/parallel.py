@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of the classification path: one process per GPU (torchrun), sequences
+sharded, tables replicated, NO collective on the data path (every sequence is independent,
+stag/classify.py:155-158).  torch.distributed is used only to bring the text rows back to
+rank 0 in input order, which is what keeps the output TSV identical to the single-process one.
+"""
+import os
+
+
+def world_rank():
+    """(world_size, rank) of the current torch.distributed job, (1, 0) outside one."""
+    try:
+        import torch.distributed as dist
+    except ImportError:
+        return 1, 0
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def local_device():
+    return int(os.environ.get("STAG_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+
+
+def shard_bounds(n, world):
+    """Contiguous index ranges [i*n/world, (i+1)*n/world)."""
+    return [((i * n) // world, ((i + 1) * n) // world) for i in range(world)]
+
+
+def owner_of_batch(batch_index, world):
+    """Batches of a stream are dealt round-robin: rank = batch index mod world."""
+    return batch_index % world
+
+
+def gather_in_order(tagged_rows, error=None):
+    """tagged_rows: list of (batch_index, rows) produced by this rank.  Returns, on rank 0, the rows
+    of all ranks flattened in batch order; on other ranks an empty list.  If any rank passes
+    an exception in ``error`` every rank raises it (so that no rank waits for a dead peer)."""
+    world, rank = world_rank()
+    if world == 1:
+        if error is not None:
+            raise error
+        return [r for _, rows in sorted(tagged_rows, key=lambda t: t[0]) for r in rows]
+    import torch.distributed as dist
+    errors = [None] * world
+    dist.all_gather_object(errors, error)
+    for e in errors:
+        if e is not None:
+            raise e
+    gathered = [None] * world if rank == 0 else None
+    dist.gather_object(tagged_rows, gathered, dst=0)
+    if rank != 0:
+        return []
+    merged = [t for part in gathered for t in part]
+    return [r for _, rows in sorted(merged, key=lambda t: t[0]) for r in rows]
+
+
+def broadcast_object(obj, src=0):
+    world, _ = world_rank()
+    if world == 1:
+        return obj
+    import torch.distributed as dist
+    box = [obj]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]

@@ -1,0 +1,174 @@
+"""CPU: host logic of the drop-in (classify(), classify_genome pieces, rank sharding) with the
+GPU engine replaced by the oracle-backed stand-in of tests/fake_engine.py.  The arithmetic is
+NOT what is under test here (tests/test_gpu_*.py do that on the real kernels); file formats,
+output text, return values, error behaviour and the world_size-2 sharding are."""
+import io
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+from fake_engine import OracleDatabase
+from oracle import oracle_np
+from stag_amd import classify as sc
+from stag_amd import classify_genome as scg
+from stag_amd import databases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = os.path.join(gu.GOLDEN, "tiny.stagDB")
+
+
+@pytest.fixture
+def fake_gpu(monkeypatch):
+    monkeypatch.setattr(sc, "Database", OracleDatabase)
+
+
+def golden_tsv_setup(monkeypatch, tmp_path):
+    g = gu.load("tsv.json")
+    taxonomy, tax_function, classifiers = gu.db_from_json(g["db"])
+
+    def fake_load_db(path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):
+        hmm = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        hmm.write("NA")
+        hmm.close()
+        return hmm.name, False, taxonomy, tax_function, classifiers, "0.8.2"
+
+    monkeypatch.setattr(sc, "load_db", fake_load_db)
+    ali = tmp_path / "ali.tsv"
+    ali.write_text("\n".join(g["ali_lines"]) + "\n")
+    return g, str(ali)
+
+
+def test_classify_output_text_matches_reference(fake_gpu, monkeypatch, tmp_path, capsys):
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)
+    out = str(tmp_path / "short.tsv")
+    ret = sc.classify("db", aligned_sequences=ali, output=out, verbose=1)
+    assert open(out).read() == g["runs"]["short"]["file"]
+    assert ret[0] == g["runs"]["short"]["return_len"] and ret[1] == g["runs"]["short"]["return_rows"]
+    assert oct(os.stat(out).st_mode & 0o777) == "0o644"
+    ret = sc.classify("db", aligned_sequences=ali, output=str(tmp_path / "long.tsv"), verbose=1, long_out=True)
+    got = open(tmp_path / "long.tsv").read().splitlines()
+    exp = g["runs"]["long"]["file"].splitlines()
+    assert got[0] == exp[0] and len(got) == len(exp)
+    for a, b in zip(got[1:], exp[1:]):
+        gu.rows_match(a.split("\t"), b.split("\t"), rtol=1e-12)
+    ret = sc.classify("db", aligned_sequences=ali, verbose=1, internal_call=True, long_out=True,
+                      output=str(tmp_path / "none"))
+    assert ret[1] == g["runs"]["internal"]["return_rows"] and not os.path.exists(tmp_path / "none")
+    capsys.readouterr()
+    sc.classify("db", aligned_sequences=ali, verbose=1)
+    assert capsys.readouterr().out == g["runs"]["stdout_short"]["file"]
+
+
+def test_classify_verbose_and_errors(fake_gpu, monkeypatch, tmp_path, capsys):
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)
+    sc.classify("db", aligned_sequences=ali, output=str(tmp_path / "o"), verbose=3)
+    err = capsys.readouterr().err
+    assert err.startswith("Load database: ") and "Classify sequences: " in err
+    bad = tmp_path / "bad.tsv"
+    bad.write_text(g["ali_lines"][0] + "\n" + "short\t0\t1\t0\n")
+    with pytest.raises(ValueError, match="broadcast"):
+        sc.classify("db", aligned_sequences=str(bad), output=str(tmp_path / "o2"), verbose=1)
+    empty = tmp_path / "empty.tsv"
+    empty.write_text("")
+    ret = sc.classify("db", aligned_sequences=str(empty), output=str(tmp_path / "o3"), verbose=1)
+    assert ret == (None, []) and open(tmp_path / "o3").read() == "sequence\ttaxonomy\n"
+
+
+def test_parse_onehot_line_matches_reference_reader():
+    for line in ("id1\t0\t1\t0\t0\t1\n", "id2\t0\t10\t0\t-3\t1\n", "id3\t1\n", "x y\t0\t0\n"):
+        gid, x = sc.parse_onehot_line(line)
+        eid, ex = oracle_np.parse_onehot_line(line)
+        assert gid == eid and np.array_equal(x, ex) and x.dtype == bool
+
+
+@pytest.mark.skipif(databases._load_h5lib() is None, reason="libstag_h5.so not built")
+def test_classify_on_reference_written_stagdb(fake_gpu, tmp_path):
+    """Whole -s path from the HDF5 file the reference's writer produced."""
+    rng = np.random.default_rng(9)
+    hmm, _, taxonomy, tax_function, classifiers, _ = databases.load_db(TINY)
+    os.remove(hmm)
+    lines, exp = [], []
+    for i in range(40):
+        sym = rng.integers(0, 5, size=29)
+        x = np.zeros(145, dtype=bool)
+        x[5 * np.arange(29) + sym] = True
+        lines.append("r%d\t%s" % (i, "\t".join("1" if b else "0" for b in x)))
+        exp.append(oracle_np.classify_seq("r%d" % i, x, taxonomy, tax_function, classifiers))
+    ali = tmp_path / "a.tsv"
+    ali.write_text("\n".join(lines) + "\n")
+    out = tmp_path / "o.tsv"
+    n, rows = sc.classify(TINY, aligned_sequences=str(ali), output=str(out), long_out=True, verbose=1)
+    assert n == 145 and len(rows) == 40
+    for a, b in zip(rows, exp):
+        gu.rows_match(a, b, rtol=1e-12)
+    assert open(out).read().splitlines()[0].split("\t") == sc.OUT_HEADER
+
+
+def test_concat_and_merge_match_reference(tmp_path):
+    g = gu.load("concat.json")
+    ali = tmp_path / "MG_ali"
+    ali.mkdir()
+    for mg, lines in g["ali_files"].items():
+        (ali / mg).write_text("\n".join(lines) + "\n")
+    path = scg.concat_alignments(None, str(ali), g["gene_order"], g["ali_lengths"])
+    assert open(path).read() == g["concatenated"]
+    os.remove(path)
+    preds = {"dir/genomeA.fna_12##COG0012": "Bacteria;Firmicutes", "dir/genomeA.fna_40##COG0016": "Bacteria",
+             "plain.3##COG0012": ""}
+    scg.merge_gene_predictions(None, [], preds, 1, 1, str(tmp_path), False, False)
+    got = (tmp_path / "genes_predictions" / "genomeA.fna").read_text().splitlines()
+    assert got == ["dir/genomeA.fna_12##COG0012\tCOG0012\tBacteria;Firmicutes",
+                   "dir/genomeA.fna_40##COG0016\tCOG0016\tBacteria"]
+    assert (tmp_path / "genes_predictions" / "plain").read_text() == "plain.3##COG0012\tCOG0012\t\n"
+
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+import stag_amd.classify as sc
+from fake_engine import OracleDatabase
+sc.Database = OracleDatabase
+sc.READER_BATCH = 7          # many small batches so both ranks own some
+n, rows = sc.classify({db!r}, aligned_sequences={ali!r}, output={out!r} + ".rank" + sys.argv[1], long_out=True, verbose=1)
+json.dump([n, rows], open({out!r} + ".ret" + sys.argv[1], "w"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.skipif(databases._load_h5lib() is None, reason="libstag_h5.so not built")
+def test_sharded_classify_world2_gloo(fake_gpu, tmp_path):
+    """Two ranks (gloo, CPU): batches dealt round-robin, rows gathered to rank 0 in input order;
+    the output file must equal the single-process one and only rank 0 writes it."""
+    rng = np.random.default_rng(10)
+    lines = []
+    for i in range(60):
+        x = np.zeros(145, dtype=bool)
+        x[5 * np.arange(29) + rng.integers(0, 5, size=29)] = True
+        lines.append("r%d\t%s" % (i, "\t".join("1" if b else "0" for b in x)))
+    ali = tmp_path / "a.tsv"
+    ali.write_text("\n".join(lines) + "\n")
+    single = tmp_path / "single.tsv"
+    n1, rows1 = sc.classify(TINY, aligned_sequences=str(ali), output=str(single), long_out=True, verbose=1)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = WORKER.format(root=ROOT, port=port, db=TINY, ali=str(ali), out=str(tmp_path / "dist"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()[-2000:]
+    assert open(str(tmp_path / "dist") + ".rank0").read() == open(single).read()
+    assert not os.path.exists(str(tmp_path / "dist") + ".rank1")
+    n0, rows0 = json.load(open(str(tmp_path / "dist") + ".ret0"))
+    assert n0 == n1 and [list(map(str, r)) for r in rows0] == [list(map(str, r)) for r in rows1]
+    assert json.load(open(str(tmp_path / "dist") + ".ret1")) == [145, []]
