@@ -89,23 +89,54 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                     wv[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
             }
         }
-        uint64_t lo = 0;
-        uint32_t hi = 0;
-        int k = 0;
+        // bytes outside [begin, end) (first and last vector of a record) become '\n' = skipped
+        if (p < begin || p + 16 > end) {
+            const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
+            const int hi_cut = (int)min((int64_t)16, max((int64_t)0, end - p));
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const uint32_t b = (wv[j >> 2] >> (8 * (j & 3))) & 0xffu;
-            const int64_t q = p + j;
-            const bool valid = q >= begin && q < end;
-            const bool skip = (b - (uint32_t)'a' < 26u) || b == '\n' || b == '\r';
-            const int code = b == 'A' ? 4 : b == 'C' ? 3 : b == 'G' ? 2 : (b == 'T' || b == 'U') ? 1 : 0;
-            if (valid && !skip) {
-                const int bit = 5 * k + code;
-                if (bit < 64) lo |= 1ull << bit; else hi |= 1u << (bit - 64);
-                ++k;
-                aligned += code != 0;
+            for (int j = 0; j < 4; ++j) {
+                const int a0 = min(4, max(0, lo_cut - 4 * j)), b0 = min(4, max(0, hi_cut - 4 * j));
+                const uint32_t below_b = b0 >= 4 ? 0xffffffffu : (1u << (8 * b0)) - 1u;
+                const uint32_t below_a = a0 >= 4 ? 0xffffffffu : (1u << (8 * a0)) - 1u;
+                const uint32_t keep = below_b & ~below_a;
+                wv[j] = (wv[j] & keep) | (0x0a0a0a0au & ~keep);
             }
         }
+        // Branch-free SWAR over the 4 dwords: classify 4 bytes at a time, pack the kept bytes'
+        // 5-bit one-hot groups densely (a skipped byte contributes no group).
+        uint32_t pk[4];
+        int cnt[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t x = wv[j];
+            const uint32_t t = x & 0x7f7f7f7fu;
+            // skipped: 'a'..'z' (HMM insert states, align.py:47) and 0x0a..0x0d (line breaks)
+            const uint32_t ge61 = t + 0x1f1f1f1fu, ge7b = t + 0x05050505u;
+            const uint32_t ge0a = t + 0x76767676u, ge0e = t + 0x72727272u;
+            const uint32_t skip80 = ((ge61 & ~ge7b) | (ge0a & ~ge0e)) & ~x & 0x80808080u;
+            // A/C/G/T/U differ in their low 3 bits (1,3,7,4,5): two byte-LUTs indexed by them give
+            // the character that index stands for and its one-hot group; any other byte is "others"
+            const uint32_t sel = x & 0x07070707u;
+            const uint32_t expc = __builtin_amdgcn_perm(0x47ff5554u, 0x43ff41ffu, sel);
+            const uint32_t oneh = __builtin_amdgcn_perm(0x04000202u, 0x08001000u, sel);
+            const uint32_t y = x ^ expc;
+            const uint32_t eq80 = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;  // byte == expected
+            const uint32_t eqm = (eq80 >> 7) * 0xffu;
+            uint32_t code = (oneh & eqm) | (0x01010101u & ~eqm);
+            code &= ~((skip80 >> 7) * 0xffu);
+            aligned += __popc(eq80);
+            const uint32_t k0 = ((skip80 >> 7) & 1u) ^ 1u, k1 = ((skip80 >> 15) & 1u) ^ 1u;
+            const uint32_t k2 = ((skip80 >> 23) & 1u) ^ 1u, k3 = (skip80 >> 31) ^ 1u;
+            const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
+            pk[j] = (code & 0x1fu) | (((code >> 8) & 0x1fu) << s1) | (((code >> 16) & 0x1fu) << s2) |
+                    ((code >> 24) << s3);
+            cnt[j] = (int)(k0 + k1 + k2 + k3);
+        }
+        const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
+        const uint64_t lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) |
+                            ((uint64_t)pk[3] << sh3);
+        const uint32_t hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
+        const int k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
         const int incl = wave_incl_scan(k, lane);
         const int total = __shfl(incl, 63);
         const int64_t bitoff = 5ll * (running + incl - k);
