@@ -45,12 +45,16 @@ using i32x4 = __attribute__((ext_vector_type(4))) int32_t;
 // ------------------------------------------------------------------------------------------
 // encode: stag/align.py:28-58 (+ the filter of :160).  One wave per aligned string.
 // ------------------------------------------------------------------------------------------
+// Inclusive prefix sum over the 64 lanes with DPP moves (no LDS traffic): Kogge-Stone inside
+// each row of 16 lanes, then the row totals are carried with row_bcast:15 / row_bcast:31.
 __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d);
-        if (lane >= d) v += t;
-    }
+    (void)lane;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2 and 3
     return v;
 }
 
@@ -77,18 +81,24 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t begin = offs[seq], end = offs[seq + 1];
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
-    for (int64_t p0 = base; p0 < end; p0 += 1024) {
-        const int64_t p = p0 + (int64_t)lane * 16;
-        uint32_t wv[4] = {0, 0, 0, 0};
+    auto load16 = [&](int64_t p, uint32_t (&o)[4]) {
+        o[0] = o[1] = o[2] = o[3] = 0;
         if (p < end) {
             if (p + 16 <= text_bytes) {
                 const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
-                wv[0] = v.x; wv[1] = v.y; wv[2] = v.z; wv[3] = v.w;
+                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
             } else {
                 for (int j = 0; j < 16 && p + j < text_bytes; ++j)
-                    wv[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
+                    o[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
             }
         }
+    };
+    uint32_t nxt[4];
+    load16(base + (int64_t)lane * 16, nxt);
+    for (int64_t p0 = base; p0 < end; p0 += 1024) {
+        const int64_t p = p0 + (int64_t)lane * 16;
+        uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
+        load16(p + 1024, nxt);   // the next vector is in flight while this one is encoded
         // bytes outside [begin, end) (first and last vector of a record) become '\n' = skipped
         if (p < begin || p + 16 > end) {
             const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
