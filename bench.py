@@ -59,6 +59,7 @@ def main():
     t = wl.tables
     n = args.reads
     text, offs, _ = bw.make_reads(wl, seed=1000 + rank, n=n)
+    text = np.concatenate([text, np.zeros(-len(text) % 16, dtype=np.uint8)])    # the _dev ABI wants a 16-byte multiple
     db = Database(t, device=local)
     D, K, W = db.max_depth, db.n_keys, db.words_per_row
     dev = torch.device("cuda", local)

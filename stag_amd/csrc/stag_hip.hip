@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -80,7 +81,9 @@ struct stag_db {
     int64_t cap_n = 0;
     DevBuf<int32_t> node, pos, order, count, node_off, task_off, n_tasks;
     DevBuf<Task> tasks;
-    DevBuf<uint32_t> bits;
+    DevBuf<uint32_t> bits, win, pat;
+    int n_cu = 256;
+    bool legacy_walk = false;   // STAG_WALK=legacy: the non-persistent kernel for every database (A/B runs)
     DevBuf<uint8_t> text;
     DevBuf<int64_t> offs;
     DevBuf<int32_t> enc_n_char, enc_status;
@@ -95,7 +98,7 @@ struct stag_db {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
         count.release(); node_off.release(); task_off.release(); n_tasks.release(); tasks.release();
-        bits.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
+        bits.release(); win.release(); pat.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
         r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
         for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -144,13 +147,15 @@ int launch_check(const char *what) {
 
 int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
                double min_perc, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned, int32_t *d_status,
-               hipStream_t st) {
+               uint32_t *d_win, hipStream_t st) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
     const size_t lds = (size_t)4 * W * sizeof(uint32_t);
     if (lds > 160 * 1024) return fail(STAG_E_INVALID, "n_features %d too large for the encode kernel's LDS row buffers", L);
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
         return fail(STAG_E_INVALID, "d_text and d_bits must be 16-byte aligned");
+    if (text_bytes & 15)
+        return fail(STAG_E_INVALID, "text_bytes (the size of the text buffer) must be a multiple of 16: pad the buffer");
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)k_encode_a2m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const int64_t grid = (n + 3) / 4;
@@ -158,7 +163,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
     {
         Prof p(db_for_prof, st, 0);
         hipLaunchKernelGGL(k_encode_a2m, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
-                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status);
+                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win);
     }
     return launch_check("k_encode_a2m");
 }
@@ -188,6 +193,7 @@ int reserve_walk(stag_db *db, int64_t n) {
     if ((rc = db->node.reserve(n))) return rc;
     if ((rc = db->pos.reserve(n))) return rc;
     if ((rc = db->order.reserve(n))) return rc;
+    if ((rc = db->win.reserve(n))) return rc;
     if ((rc = db->tasks.reserve(n / TILE + db->max_level_nodes + 2))) return rc;
     if ((rc = db->count.reserve(db->n_nodes))) return rc;
     if ((rc = db->node_off.reserve(db->n_nodes))) return rc;
@@ -223,7 +229,7 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     if (count_aligned) {
         Prof p(db, st, 4);
         hipLaunchKernelGGL(k_count_aligned, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_bits, n, db->L, db->W,
-                           o.n_aligned);
+                           o.n_aligned, db->win.p);
     }
     {
         Prof p(db, st, 2);
@@ -251,10 +257,15 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
         a.child_first = db->child_first.p; a.node_err = db->node_err.p; a.intercept = db->intercept.p;
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p; a.node = db->node.p;
         a.path_node = o.path_node; a.path_prob = o.path_prob; a.path_len = o.path_len; a.status = o.status;
+        a.win = db->win.p; a.pat = db->pat.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
             Prof p(db, st, 1);
-            hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
+            if (db->nchunks == 1 && !db->legacy_walk)   // persistent workgroups, 2 per CU (LDS-limited)
+                hipLaunchKernelGGL(k_walk_level_win, dim3((unsigned)std::min<int64_t>(max_tasks, 2 * db->n_cu)),
+                                   dim3(NW * 64), 0, st, a);
+            else
+                hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
         }
         if ((rc = launch_check("k_walk_level"))) return rc;
     }
@@ -406,6 +417,21 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     std::vector<int32_t> cf(t->child_first, t->child_first + n + 1);
     std::vector<double> ic(t->intercept, t->intercept + n);
     std::vector<double> tfv(t->tf ? t->tf : nullptr, t->tf ? t->tf + (size_t)t->n_keys * (1 + t->n_tf) : nullptr);
+    // the all-gaps row R0 (same formula as r0_word() on the device)
+    std::vector<uint32_t> pat(db->W, 0u);
+    for (int w = 0; w < db->W; ++w)
+        for (int i = 0; i < 32; ++i) {
+            const int64_t f = 32ll * w + i;
+            if (f < db->L && f % 5 == 0) pat[w] |= 1u << i;
+        }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+            db->n_cu = prop.multiProcessorCount;
+        const char *mode = getenv("STAG_WALK");
+        db->legacy_walk = mode && strcmp(mode, "legacy") == 0;
+    }
+    UP(pat, pat, uint32_t);
     UP(child_first, cf, int32_t);
     UP(node_err, node_err, uint8_t);
     UP(intercept, ic, double);
@@ -457,7 +483,7 @@ int stag_encode_a2m_dev(int32_t n_features, const char *d_text, int64_t text_byt
     if (n < 0 || n_features < 1 || (n > 0 && (!d_text || !d_offs || !d_bits || !d_n_char || !d_n_aligned || !d_status)))
         return fail(STAG_E_INVALID, "bad argument");
     return encode_dev(nullptr, n_features, d_text, text_bytes, d_offs, n, min_perc_state, d_bits, d_n_char, d_n_aligned,
-                      d_status, (hipStream_t)stream);
+                      d_status, nullptr, (hipStream_t)stream);
 }
 
 int stag_encode_a2m(int32_t device, int32_t n_features, const char *text, const int64_t *offs, int64_t n,
@@ -480,8 +506,8 @@ int stag_encode_a2m(int32_t device, int32_t n_features, const char *text, const 
     if (hipMemcpy(d_text.p, text, text_bytes, hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(d_offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess)
         return done(fail(STAG_E_HIP, "host to device copy failed"));
-    rc = encode_dev(nullptr, n_features, (const char *)d_text.p, text_bytes, d_offs.p, n, min_perc_state, d_bits.p, d_i.p,
-                    d_i.p + n, d_i.p + 2 * n, nullptr);
+    rc = encode_dev(nullptr, n_features, (const char *)d_text.p, (text_bytes + 15) / 16 * 16, d_offs.p, n, min_perc_state, d_bits.p, d_i.p,
+                    d_i.p + n, d_i.p + 2 * n, nullptr, nullptr);
     if (rc) return done(rc);
     if (hipMemcpy(bits, d_bits.p, (size_t)n * W * 4, hipMemcpyDeviceToHost) != hipSuccess ||
         hipMemcpy(n_char, d_i.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -525,7 +551,7 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
     const Out o = resolve(db, d_out);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = encode_dev(db, db->L, d_text, text_bytes, d_offs, n, min_perc_state, db->bits.p, db->enc_n_char.p,
-                         o.n_aligned, db->enc_status.p, st)))
+                         o.n_aligned, db->enc_status.p, db->win.p, st)))
         return rc;
     return walk_dev(db, db->bits.p, n, db->enc_status.p, o, false, st);
 }
@@ -543,7 +569,7 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         return rc;
     HIP_TRY(hipMemcpy(db->text.p, text, text_bytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db->offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    if ((rc = stag_classify_a2m_dev(db, (const char *)db->text.p, text_bytes, db->offs.p, n, min_perc_state, nullptr,
+    if ((rc = stag_classify_a2m_dev(db, (const char *)db->text.p, (text_bytes + 15) / 16 * 16, db->offs.p, n, min_perc_state, nullptr,
                                     nullptr)))
         return rc;
     if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;

@@ -64,12 +64,26 @@ __device__ __forceinline__ int wave_sum(int v) {
     return v;
 }
 
+// Word w of the "all gaps" row R0: bit 0 ("others") of every alignment column set, i.e. the
+// features f < L with f % 5 == 0.  Amplicon reads equal R0 outside the stretch of columns they
+// cover, so the walk stages only each row's *window* = the 4-word-aligned range outside which
+// the row equals R0 (win = lo4 | hi4 << 16, in units of 4 words; lo4 >= hi4: empty).
+__device__ __forceinline__ uint32_t r0_word(int w, int L) {
+    const int s = (5 - (2 * w) % 5) % 5;   // 32 = 2 (mod 5): first bit of word w that starts a column
+    uint32_t v = (uint32_t)(0x1084210842108421ull << s);
+    const int64_t nbits = (int64_t)L - 32ll * w;
+    if (nbits <= 0) v = 0;
+    else if (nbits < 32) v &= (1u << nbits) - 1u;
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ text, int64_t text_bytes,
                                                     const int64_t *__restrict__ offs, int64_t n, int L, int W,
                                                     double min_perc, uint32_t *__restrict__ rows,
                                                     int32_t *__restrict__ n_char_out,
                                                     int32_t *__restrict__ n_aligned_out,
-                                                    int32_t *__restrict__ status_out) {
+                                                    int32_t *__restrict__ status_out,
+                                                    uint32_t *__restrict__ win_out) {
     extern __shared__ uint32_t s_enc[];  // 4 waves x W words
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -81,17 +95,12 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t begin = offs[seq], end = offs[seq + 1];
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
+    // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
+    // entirely inside the buffer or entirely outside the record
     auto load16 = [&](int64_t p, uint32_t (&o)[4]) {
-        o[0] = o[1] = o[2] = o[3] = 0;
-        if (p < end) {
-            if (p + 16 <= text_bytes) {
-                const uint4 v = *reinterpret_cast<const uint4 *>(text + p);
-                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-            } else {
-                for (int j = 0; j < 16 && p + j < text_bytes; ++j)
-                    o[j >> 2] |= (uint32_t)text[p + j] << (8 * (j & 3));
-            }
-        }
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (p < end && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     };
     uint32_t nxt[4];
     load16(base + (int64_t)lane * 16, nxt);
@@ -163,11 +172,23 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     }
     aligned = wave_sum(aligned);
     uint32_t *dst = rows + (size_t)seq * W;
-    for (int w = lane * 4; w < W; w += 256) {
-        uint4 v;
-        v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
-        *reinterpret_cast<uint4 *>(dst + w) = v;
+    int lo4 = 0xffff, hi4 = 0;
+    for (int w = lane * 4, it = 0; it * 256 < W; w += 256, ++it) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        bool differs = false;
+        if (w < W) {
+            v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
+            *reinterpret_cast<uint4 *>(dst + w) = v;
+            differs = ((v.x ^ r0_word(w, L)) | (v.y ^ r0_word(w + 1, L)) | (v.z ^ r0_word(w + 2, L)) |
+                       (v.w ^ r0_word(w + 3, L))) != 0u;
+        }
+        const unsigned long long d = __ballot(differs);
+        if (d) {
+            lo4 = min(lo4, it * 64 + (int)__ffsll((long long)d) - 1);
+            hi4 = max(hi4, it * 64 + 64 - (int)__clzll((long long)d));
+        }
     }
+    if (lane == 0 && win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
     if (lane == 0) {
         int st = 0;  // STAG_SEQ_OK
         if (running == 0) st = 5;
@@ -179,20 +200,35 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     }
 }
 
-// find_n_aligned_characters (classify.py:79-87) for rows that did not come from k_encode_a2m.
+// find_n_aligned_characters (classify.py:79-87) and the R0 window for rows that did not come
+// from k_encode_a2m.
 __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restrict__ rows, int64_t n, int L, int W,
-                                                       int32_t *__restrict__ n_aligned) {
+                                                       int32_t *__restrict__ n_aligned,
+                                                       uint32_t *__restrict__ win_out) {
     const int lane = threadIdx.x & 63;
     const int64_t seq = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seq >= n) return;
     const uint32_t *row = rows + (size_t)seq * W;
-    int gaps = 0;
-    for (int w = lane; w < W; w += 64) {
-        const int s = (5 - (int)((32ll * w) % 5)) % 5;  // first bit of this word that is bit 0 of a column
-        gaps += __popc(row[w] & (uint32_t)(0x1084210842108421ull << s));
+    int gaps = 0, lo = 0x3ffff, hi = 0;
+    for (int w0 = 0; w0 < W; w0 += 64) {
+        const int w = w0 + lane;
+        bool differs = false;
+        if (w < W) {
+            const uint32_t x = row[w], r0 = r0_word(w, L);
+            gaps += __popc(x & r0);
+            differs = x != r0;
+        }
+        const unsigned long long d = __ballot(differs);
+        if (d) {
+            lo = min(lo, w0 + (int)__ffsll((long long)d) - 1);
+            hi = max(hi, w0 + 64 - (int)__clzll((long long)d));
+        }
     }
     gaps = wave_sum(gaps);
-    if (lane == 0) n_aligned[seq] = (L + 4) / 5 - gaps;
+    if (lane == 0) {
+        n_aligned[seq] = (L + 4) / 5 - gaps;
+        if (win_out) win_out[seq] = hi > lo ? (uint32_t)(lo >> 2) | ((uint32_t)((hi + 3) >> 2) << 16) : 0xffffu;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -340,6 +376,8 @@ struct WalkArgs {
     double *path_prob;          // [n][D]  (2.0 = "single child" placeholder, classify.py:37)
     int32_t *path_len;
     int32_t *status;
+    const uint32_t *win;        // [n] R0 window of each row (lo4 | hi4 << 16) or NULL
+    const uint32_t *pat;        // [W] the R0 row
 };
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
@@ -486,6 +524,185 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         } else {
             a.node[seq] = -1;  // every probability was NaN: the reference stops here (classify.py:49)
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// walk, one-chunk rows (L <= 7,680): persistent workgroups + windowed staging.
+// Same arithmetic as k_walk_level.  Differences: (1) a workgroup loops over tasks, so its LDS
+// rows keep the all-gaps row R0 everywhere except the current task's window; only the window
+// (the union of the 64 rows' windows, see r0_word) is read from HBM: for 253-column amplicon
+// reads in a 1,500-column alignment that is 168 B per row instead of 944 B; (2) the next
+// task's window is fetched into registers before the current task is scored, so the loads
+// overlap the scoring.
+// ------------------------------------------------------------------------------------------
+constexpr int ROWS_PER_WAVE = TILE / NW;
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+__global__ __launch_bounds__(NW * 64) void k_walk_level_win(WalkArgs a) {
+    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
+    __shared__ uint32_t s_pat[CHUNK_WORDS];
+    __shared__ double s_z[NW][TILE];
+    __shared__ int s_c[NW][TILE];
+
+    const int n_tasks = *as_const(a.n_tasks);
+    const int32_t STAG_CONST *child_first = as_const(a.child_first);
+    const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
+    const u32x4 STAG_CONST *blocks = as_const(reinterpret_cast<const u32x4 *>(a.blocks));
+    const i32x4 STAG_CONST *tasks = as_const(reinterpret_cast<const i32x4 *>(a.tasks));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const char *my_row = reinterpret_cast<const char *>(s_rows + lane * ROW_STRIDE);
+
+    for (int w = threadIdx.x; w < CHUNK_WORDS; w += NW * 64) s_pat[w] = w < a.W ? a.pat[w] : 0u;
+    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr)
+        for (int w = lane; w < CHUNK_WORDS; w += 64) s_rows[(rr * NW + wave) * ROW_STRIDE + w] = w < a.W ? a.pat[w] : 0u;
+
+    // ---- prefetch state of the NEXT task
+    int seq_n = -1, A_n = 0, Wd_n = 0, node_n = 0, k_n = 0;
+    uint32_t v[ROWS_PER_WAVE][4];
+    auto prefetch = [&](int task) {
+        const i32x4 tk = tasks[task];
+        node_n = tk.x;
+        seq_n = lane < tk.z ? a.order[tk.y + lane] : -1;
+        k_n = child_first[node_n + 1] - child_first[node_n];
+        A_n = 0;
+        Wd_n = 0;
+        if (k_n < 2 || a.node_err[node_n]) return;   // nothing is scored: no rows needed
+        int lo = 0xffff, hi = 0;
+        if (seq_n >= 0) {
+            const uint32_t wn = a.win ? a.win[seq_n] : ((uint32_t)(a.W >> 2) << 16);
+            lo = (int)(wn & 0xffffu);
+            hi = (int)(wn >> 16);
+            if (hi <= lo) { lo = 0xffff; hi = 0; }
+        }
+        lo = wave_min_i(lo);
+        hi = wave_max_i(hi);
+        if (hi <= lo) return;                          // every row equals R0
+        A_n = 4 * lo;
+        Wd_n = min(4 * (hi - lo), a.W - A_n);
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+            const int s = __shfl(seq_n, rr * NW + wave);  // wave-uniform
+            const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + A_n;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int w = lane + 64 * i;
+                v[rr][i] = (s >= 0 && w < Wd_n) ? src[w] : 0u;
+            }
+        }
+    };
+
+    int task = blockIdx.x;
+    if (task < n_tasks) prefetch(task);
+    while (task < n_tasks) {
+        const int seq = seq_n, A = A_n, Wd = Wd_n, node = node_n, k = k_n;
+        const int c0 = child_first[node];
+        // ---- window of this task: registers -> LDS (rows beyond the task's count stay R0)
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+            const int s = __shfl(seq, rr * NW + wave);
+            uint32_t *d = s_rows + (rr * NW + wave) * ROW_STRIDE + A;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (s >= 0 && lane + 64 * i < Wd) d[lane + 64 * i] = v[rr][i];
+        }
+        __syncthreads();
+        const int next = task + gridDim.x;
+        if (next < n_tasks) prefetch(next);   // its loads are in flight while this task is scored
+
+        if (k == 1 || a.node_err[node]) {
+            if (wave == 0 && seq >= 0) {
+                if (k == 1) {
+                    a.path_node[(size_t)seq * a.D + a.depth] = c0;
+                    a.path_prob[(size_t)seq * a.D + a.depth] = 2.0;
+                    a.path_len[seq] = a.depth + 1;
+                    a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
+                } else {
+                    a.status[seq] = a.node_err[node];
+                    a.node[seq] = -1;
+                }
+            }
+        } else {
+            double best_p = -1.0;
+            int best_c = -1;
+            for (int pass0 = 0; pass0 < k; pass0 += NW) {
+                const int kk = min(NW, k - pass0);
+                const int P = NW / kk;
+                const int ci = wave / P, part = wave - ci * P;
+                const bool active = ci < kk;
+                const int c = c0 + pass0 + ci;
+                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+                if (active) {
+                    const uint32_t b0 = blk_off[c], b1 = blk_off[c + 1];
+                    for (uint32_t b = b0 + part; b < b1; b += P) {
+                        const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
+                        const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5], e6 = e[6], e7 = e[7];
+                        z0 += masked_weight(my_row, e0);
+                        z1 += masked_weight(my_row, e1);
+                        z2 += masked_weight(my_row, e2);
+                        z3 += masked_weight(my_row, e3);
+                        z0 += masked_weight(my_row, e4);
+                        z1 += masked_weight(my_row, e5);
+                        z2 += masked_weight(my_row, e6);
+                        z3 += masked_weight(my_row, e7);
+                    }
+                }
+                double z = (z0 + z1) + (z2 + z3);
+                if (P > 1) {
+                    s_z[wave][lane] = z;
+                    __syncthreads();
+                    if (active && part == 0) {
+                        z = 0.0;
+                        for (int j = 0; j < P; ++j) z += s_z[wave + j][lane];
+                    }
+                    __syncthreads();
+                }
+                if (active && part == 0) {
+                    const double p = sigmoid(z + as_const(a.intercept)[c]);
+                    if (p > best_p) { best_p = p; best_c = c; }
+                }
+            }
+            s_z[wave][lane] = best_p;
+            s_c[wave][lane] = best_c;
+            __syncthreads();
+            if (wave == 0 && seq >= 0) {
+                for (int w = 1; w < NW; ++w) {
+                    const double p = s_z[w][lane];
+                    const int cc = s_c[w][lane];
+                    if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
+                }
+                if (best_c >= 0) {
+                    a.path_node[(size_t)seq * a.D + a.depth] = best_c;
+                    a.path_prob[(size_t)seq * a.D + a.depth] = best_p;
+                    a.path_len[seq] = a.depth + 1;
+                    a.node[seq] = a.child_first[best_c + 1] > a.child_first[best_c] ? best_c : -1;
+                } else {
+                    a.node[seq] = -1;
+                }
+            }
+        }
+        __syncthreads();   // every wave is done with the rows (and with s_z / s_c)
+        // ---- put R0 back into the window (each wave restores the rows it wrote)
+#pragma unroll
+        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
+            const int s = __shfl(seq, rr * NW + wave);
+            uint32_t *d = s_rows + (rr * NW + wave) * ROW_STRIDE + A;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (s >= 0 && lane + 64 * i < Wd) d[lane + 64 * i] = s_pat[A + lane + 64 * i];
+        }
+        task = next;
     }
 }
 
