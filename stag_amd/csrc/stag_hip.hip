@@ -81,9 +81,8 @@ struct stag_db {
     int64_t cap_n = 0;
     DevBuf<int32_t> node, pos, order, count, node_off, task_off, n_tasks;
     DevBuf<Task> tasks;
-    DevBuf<uint32_t> bits, win, pat;
-    int n_cu = 256;
-    bool legacy_walk = false;   // STAG_WALK=legacy: the non-persistent kernel for every database (A/B runs)
+    DevBuf<uint32_t> bits, win;
+    DevBuf<double> chunkgap;
     DevBuf<uint8_t> text;
     DevBuf<int64_t> offs;
     DevBuf<int32_t> enc_n_char, enc_status;
@@ -98,7 +97,7 @@ struct stag_db {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
         count.release(); node_off.release(); task_off.release(); n_tasks.release(); tasks.release();
-        bits.release(); win.release(); pat.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
+        bits.release(); win.release(); chunkgap.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
         r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
         for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -252,20 +251,16 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
-        a.bits = d_bits; a.W = db->W; a.nchunks = db->nchunks; a.depth = d; a.D = D;
+        a.bits = d_bits; a.W = db->W; a.NC = db->nchunks; a.depth = d; a.D = D;
         a.n_tasks = db->n_tasks.p + d; a.tasks = db->tasks.p; a.order = db->order.p;
         a.child_first = db->child_first.p; a.node_err = db->node_err.p; a.intercept = db->intercept.p;
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p; a.node = db->node.p;
         a.path_node = o.path_node; a.path_prob = o.path_prob; a.path_len = o.path_len; a.status = o.status;
-        a.win = db->win.p; a.pat = db->pat.p;
+        a.win = db->win.p; a.chunkgap = db->chunkgap.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
             Prof p(db, st, 1);
-            if (db->nchunks == 1 && !db->legacy_walk)   // persistent workgroups, 2 per CU (LDS-limited)
-                hipLaunchKernelGGL(k_walk_level_win, dim3((unsigned)std::min<int64_t>(max_tasks, 2 * db->n_cu)),
-                                   dim3(NW * 64), 0, st, a);
-            else
-                hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
+            hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
         }
         if ((rc = launch_check("k_walk_level"))) return rc;
     }
@@ -373,9 +368,11 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
         if (node_err[p]) for (int c = c0; c < c1; ++c) evaluated[c] = 0;
     }
 
-    // coefficient blocks
+    // coefficient blocks per (row, 16-word chunk) and the per-chunk prefix sums of the
+    // coefficients on "others" bits (feature % 5 == 0): what the all-gaps row R0 scores
     const int nch = db->nchunks;
     std::vector<uint32_t> blk_off((size_t)n * nch + 1, 0);
+    std::vector<double> chunkgap((size_t)n * nch + 8, 0.0);   // +8: the kernel fetches 8 at a time
     std::vector<Entry> entries;
     for (int c = 0; c < n; ++c) {
         int64_t e = t->row_off[c];
@@ -385,6 +382,7 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
         for (int ch = 0; ch < nch; ++ch) {
             blk_off[(size_t)c * nch + ch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
             if (!evaluated[c]) continue;
+            double gap = 0.0;   // same additions, same order, as the kernel does for a row equal to R0
             const int64_t f_end = (int64_t)(ch + 1) * CHUNK_WORDS * 32;
             while (e < e1 && t->row_feat[e] < f_end) {
                 const int f = t->row_feat[e];
@@ -394,14 +392,18 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
                 }
                 prev = f;
                 Entry en;
-                en.off = 4u * (uint32_t)((f >> 5) - ch * CHUNK_WORDS);
+                en.off = 4u * (uint32_t)(f >> 5);
                 en.bit = (uint32_t)(f & 31);
                 en.w = t->row_w[e];
+                if (f % 5 == 0) gap += en.w;   // the others contribute +0.0 in the kernel
                 entries.push_back(en);
                 ++e;
             }
-            while (entries.size() % BLOCK_ENTRIES) entries.push_back(Entry{0u, 0u, 0.0});
+            const uint32_t pad_off = 4u * (uint32_t)(ch * CHUNK_WORDS);   // padding reads a staged word
+            while (entries.size() % BLOCK_ENTRIES) entries.push_back(Entry{pad_off, 0u, 0.0});
+            chunkgap[(size_t)c * nch + ch] = gap;
         }
+        if (evaluated[c] && e != e1) { delete db; return fail(STAG_E_INVALID, "row %d: feature out of range", c); }
         if (entries.size() / BLOCK_ENTRIES > 0x7fffffffull) { delete db; return fail(STAG_E_INVALID, "coefficient table too large"); }
     }
     blk_off[(size_t)n * nch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
@@ -417,21 +419,7 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     std::vector<int32_t> cf(t->child_first, t->child_first + n + 1);
     std::vector<double> ic(t->intercept, t->intercept + n);
     std::vector<double> tfv(t->tf ? t->tf : nullptr, t->tf ? t->tf + (size_t)t->n_keys * (1 + t->n_tf) : nullptr);
-    // the all-gaps row R0 (same formula as r0_word() on the device)
-    std::vector<uint32_t> pat(db->W, 0u);
-    for (int w = 0; w < db->W; ++w)
-        for (int i = 0; i < 32; ++i) {
-            const int64_t f = 32ll * w + i;
-            if (f < db->L && f % 5 == 0) pat[w] |= 1u << i;
-        }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
-            db->n_cu = prop.multiProcessorCount;
-        const char *mode = getenv("STAG_WALK");
-        db->legacy_walk = mode && strcmp(mode, "legacy") == 0;
-    }
-    UP(pat, pat, uint32_t);
+    UP(chunkgap, chunkgap, double);
     UP(child_first, cf, int32_t);
     UP(node_err, node_err, uint8_t);
     UP(intercept, ic, double);

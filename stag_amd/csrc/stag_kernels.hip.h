@@ -3,10 +3,15 @@
 // Data layout in HBM
 //   packed rows   uint32[n][W]   bit f of sequence i = one-hot feature f (word f>>5, bit f&31),
 //                                W = ceil(L/32) rounded up to 4 words (16-byte rows)
+//   row windows   uint32[n]      the 4-word-aligned range outside which a row equals the
+//                                "all gaps" row R0 (bit 0 of every column set), see r0_word()
 //   coefficient blocks           each child row's NON-ZERO coefficients, sorted by feature, cut
-//                                at CHUNK_WORDS-word boundaries and padded per (row, chunk) to
-//                                blocks of 8 entries {byte offset, bit, fp64 w} = 128 B, so that two
-//                                s_load_dwordx16 fetch a block into SGPRs for a whole wave
+//                                into chunks of CHUNK_WORDS = 16 row words (512 features, 64 B of
+//                                a row) and padded per (row, chunk) to blocks of 4 entries
+//                                {byte offset in row, bit, fp64 w} = 64 B = one s_load_dwordx16;
+//                                blk_off[row * NC + chunk] indexes them
+//   chunk gaps    double[n_nodes][NC]  per chunk, the sum of the coefficients that sit on a column's
+//                                "others" bit: what R0 scores in that chunk
 //   grouping      node[n], pos[n], order[n], tasks[]: sequences sorted by current tree node,
 //                                cut into tasks of <= 64 sequences of one node
 #pragma once
@@ -17,12 +22,13 @@ namespace stagk {
 
 constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
 constexpr int NW = 8;             // waves per walk workgroup (all share the 64 staged rows)
-constexpr int CHUNK_WORDS = 240;  // packed-row words staged in LDS per pass (7,680 features)
-constexpr int ROW_STRIDE = CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
-constexpr int BLOCK_ENTRIES = 8;   // entries per scalar fetch (2 x s_load_dwordx16)
+constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-byte sector of a row)
+constexpr int WCAP_CHUNKS = 5;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
+constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
+constexpr int BLOCK_ENTRIES = 4;  // entries per scalar fetch (one s_load_dwordx16)
 
 struct Entry {      // 16 bytes
-    uint32_t off;   // byte offset of the feature's word inside the staged chunk of a row
+    uint32_t off;   // byte offset of the feature's word inside the row
     uint32_t bit;   // feature & 31
     double w;       // 0.0 for padding entries
 };
@@ -356,28 +362,39 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
 
 // ------------------------------------------------------------------------------------------
 // walk: one tree level.  stag/classify.py:22-52 for all sequences standing at nodes of level
-// `depth`.  One workgroup = up to 64 sequences of ONE node (lane = sequence): their packed
-// rows are staged in LDS, the siblings' non-zero coefficients arrive as wave-uniform scalar
-// loads and every lane adds the coefficients whose feature bit is set in its own row.
+// `depth`.  One workgroup = up to 64 sequences of ONE node (lane = sequence).
+//
+//  * Only the task's WINDOW of the rows is read: the union of the 64 rows' windows, rounded to
+//    16-word chunks (64-byte sectors).  Outside it every row equals R0, so a sibling's score
+//    there is a constant: the sum of its coefficients on "others" bits, kept per chunk
+//    (chunkgap).  z = intercept + chunkgap(chunks outside the window) + sum over the coefficients
+//    INSIDE the window whose feature bit is set in the lane's row.  For 253-column amplicon
+//    reads in a 1,500-column alignment that is 256 B instead of 944 B per row and a sixth of
+//    the coefficients; for rows that differ from R0 everywhere it degrades to the full row.
+//  * The window slice of the rows is staged in LDS ([row][word], odd stride: lane l reading
+//    word w is conflict-free); WCAP_CHUNKS chunks at a time, wider windows loop.
+//  * Sibling rows are dealt to the 8 waves; a wave streams its sibling's coefficient blocks of
+//    the window through scalar loads (one s_load_dwordx16 = 4 coefficients for all 64 lanes)
+//    and every lane adds w & -(bit): v_add, ds_read_b32, v_bfe_i32, 2 x v_and, v_add_f64.
 // ------------------------------------------------------------------------------------------
 struct WalkArgs {
     const uint32_t *bits;       // [n][W]
-    int W, nchunks, depth, D;
+    int W, NC, depth, D;        // NC = chunks per row
     const int32_t *n_tasks;
     const Task *tasks;
     const int32_t *order;
     const int32_t *child_first;
     const uint8_t *node_err;    // per parent: status every sequence reaching it gets (0 = fine)
     const double *intercept;
-    const uint32_t *blk_off;    // [n_nodes*nchunks + 1]
+    const uint32_t *blk_off;    // [n_nodes*NC + 1]
+    const double *chunkgap;     // [n_nodes][NC] (+8 padding): sum of a chunk's coefficients on "others" bits
     const uint4 *blocks;        // Entry[4] per block
     int32_t *node;              // [n] in: current node; out: next node or -1
     int32_t *path_node;         // [n][D]
     double *path_prob;          // [n][D]  (2.0 = "single child" placeholder, classify.py:37)
     int32_t *path_len;
     int32_t *status;
-    const uint32_t *win;        // [n] R0 window of each row (lo4 | hi4 << 16) or NULL
-    const uint32_t *pat;        // [W] the R0 row
+    const uint32_t *win;        // [n] R0 window of each row (lo4 | hi4 << 16, units of 4 words)
 };
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
@@ -389,25 +406,51 @@ __device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 
     return __hiloint2double((int)e.w & m, (int)e.z & m);
 }
 
+// z += chunkgap[ch] for the chunks lo <= ch < hi of this wave's class (ch % P == part), in
+// increasing order.  Values arrive 8 at a time through one scalar load (the array is padded).
+__device__ __forceinline__ double add_outside(double z, const double STAG_CONST *cg, int lo, int hi, int part, int P) {
+    for (int g = lo & ~7; g < hi; g += 8) {
+        double d[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] = cg[g + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ch = g + j;
+            if (ch >= lo && ch < hi && ((ch & (P - 1)) == part)) z += d[j];
+        }
+    }
+    return z;
+}
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
     __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
     __shared__ double s_z[NW][TILE];
     __shared__ int s_c[NW][TILE];
 
     if ((int)blockIdx.x >= *as_const(a.n_tasks)) return;
-    const i32x4 tkv = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];
-    Task tk;
-    tk.node = tkv.x; tk.start = tkv.y; tk.count = tkv.z; tk.pad = 0;
+    const i32x4 tk = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];  // node, start, count
     const int32_t STAG_CONST *child_first = as_const(a.child_first);
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
     const u32x4 STAG_CONST *blocks = as_const(reinterpret_cast<const u32x4 *>(a.blocks));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int seq = lane < tk.count ? a.order[tk.start + lane] : -1;
-    const int c0 = child_first[tk.node];
-    const int k = child_first[tk.node + 1] - c0;
+    const int node = tk.x;
+    const int seq = lane < tk.z ? a.order[tk.y + lane] : -1;
+    const int c0 = child_first[node];
+    const int k = child_first[node + 1] - c0;
 
-    if (k == 1 || a.node_err[tk.node]) {  // nothing to score (classify.py:35-37) or the reference raises
+    if (k == 1 || a.node_err[node]) {  // nothing to score (classify.py:35-37) or the reference raises
         if (wave == 0 && seq >= 0) {
             if (k == 1) {
                 a.path_node[(size_t)seq * a.D + a.depth] = c0;
@@ -415,85 +458,89 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
                 a.path_len[seq] = a.depth + 1;
                 a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
             } else {
-                a.status[seq] = a.node_err[tk.node];
+                a.status[seq] = a.node_err[node];
                 a.node[seq] = -1;
             }
         }
         return;
     }
 
+    // ---- the task's window in chunks [cA, cB): union of its rows' windows
+    int lo = 0x7fff, hi = 0;
+    if (seq >= 0) {
+        const uint32_t wn = a.win[seq];
+        const int l4 = (int)(wn & 0xffffu), h4 = (int)(wn >> 16);
+        if (h4 > l4) { lo = l4 >> 2; hi = (h4 + 3) >> 2; }   // 4-word units -> 16-word chunks
+    }
+    const int cA = wave_min_i(lo);
+    const int cB = min(wave_max_i(hi), a.NC);
+    const bool one_slice = cB - cA <= WCAP_CHUNKS;   // the usual case: staged once for all siblings
+
     // Siblings are scored NW at a time ("pass"), one per wave; a pass with fewer than NW
-    // siblings splits each sibling's blocks over P = NW / siblings waves.  Which blocks a wave
-    // sums depends only on (sibling's block index, P), so identical rows give identical sums
-    // and exact ties resolve to the first stored child like the reference's strict '>'.
+    // siblings gives each sibling P = NW / siblings waves (a power of two), wave `part` taking the
+    // chunks ch with ch % P == part.
+    //
+    // CANONICAL SUMMATION.  A wave adds, in increasing chunk order, one term per chunk of its
+    // class: inside the window the lane's own sum over that chunk's coefficients (in stored
+    // order, one accumulator), outside it chunkgap[ch], which the host computed with the same
+    // additions for a row that equals R0 there.  So a score depends only on (row, node): not on
+    // which other rows share the task, nor on how wide the task's window is.  That keeps
+    // results bit-identical from run to run (task composition comes from atomics) and makes
+    // identical sibling rows tie exactly, so the first stored child wins as in classify.py:41.
     double best_p = -1.0;
     int best_c = -1;
-    const char *my_row = reinterpret_cast<const char *>(s_rows + lane * ROW_STRIDE);
-
+    const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
     for (int pass0 = 0; pass0 < k; pass0 += NW) {
         const int kk = min(NW, k - pass0);
         const int P = NW / kk;
         const int ci = wave / P, part = wave - ci * P;
         const bool active = ci < kk;
         const int c = c0 + pass0 + ci;
-        double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-        for (int ch = 0; ch < a.nchunks; ++ch) {
-            if (a.nchunks > 1 || pass0 == 0) {  // a one-chunk row is staged once for all passes
-                const int cw = min(CHUNK_WORDS, a.W - ch * CHUNK_WORDS);
-                __syncthreads();  // everyone is done reading the previous chunk
-#ifndef STAG_ABLATE_NO_STAGE
-                // One row per wave and step, lanes over consecutive words: 256-byte coalesced
-                // loads, and LDS stores that hit 32 different banks (a uint4 per lane would put
-                // every fourth dword of a row on the same bank: 4-way conflicts on each store).
-                static_assert(CHUNK_WORDS <= 4 * 64, "staging loop covers a chunk in four 64-word steps");
+        const double STAG_CONST *cg = as_const(a.chunkgap) + (size_t)c * a.NC;
+        const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
+        double z = 0.0;
+        if (active) z = add_outside(z, cg, 0, wA, part, P);
+        for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
+            const int sB = min(wB, sA + WCAP_CHUNKS);
+            if (!one_slice || pass0 == 0) {
+                const int w0 = sA * CHUNK_WORDS;
+                const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= 80 words
+                __syncthreads();  // everyone is done reading the previous slice
+                // one row per wave and step, lanes over consecutive words: coalesced loads and
+                // LDS stores on 32 different banks
 #pragma unroll
-                for (int r0 = 0; r0 < TILE; r0 += 4 * NW) {
-                    uint32_t v[4][4];
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        const int r = r0 + rr * NW + wave;
-                        const int s = __shfl(seq, r);  // wave-uniform
-                        const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + ch * CHUNK_WORDS;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const int w = lane + 64 * i;
-                            v[rr][i] = (s >= 0 && w < cw) ? src[w] : 0u;
-                        }
-                    }
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr) {
-                        uint32_t *d = s_rows + (r0 + rr * NW + wave) * ROW_STRIDE;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (lane + 64 * i < CHUNK_WORDS) d[lane + 64 * i] = v[rr][i];
-                    }
+                for (int rr = 0; rr < TILE / NW; ++rr) {
+                    const int r = rr * NW + wave;
+                    const int s = __shfl(seq, r);  // wave-uniform
+                    const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + w0;
+                    const uint32_t v0 = (s >= 0 && lane < width) ? src[lane] : 0u;
+                    const uint32_t v1 = (s >= 0 && lane + 64 < width) ? src[lane + 64] : 0u;
+                    s_rows[r * ROW_STRIDE + lane] = v0;
+                    if (lane + 64 < ROW_STRIDE - 1) s_rows[r * ROW_STRIDE + lane + 64] = v1;
                 }
-#endif
                 __syncthreads();
             }
-#ifndef STAG_ABLATE_NO_ENTRIES
             if (active) {
-                const uint32_t seg = (uint32_t)c * a.nchunks + ch;
-                const uint32_t b0 = blk_off[seg], b1 = blk_off[seg + 1];
-                for (uint32_t b = b0 + part; b < b1; b += P) {
-                    const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
-                    const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5], e6 = e[6], e7 = e[7];
-                    z0 += masked_weight(my_row, e0);
-                    z1 += masked_weight(my_row, e1);
-                    z2 += masked_weight(my_row, e2);
-                    z3 += masked_weight(my_row, e3);
-                    z0 += masked_weight(my_row, e4);
-                    z1 += masked_weight(my_row, e5);
-                    z2 += masked_weight(my_row, e6);
-                    z3 += masked_weight(my_row, e7);
+                // entry offsets are relative to the row; the slice starts at chunk sA
+                const char *my_row = reinterpret_cast<const char *>(s_rows) +
+                                     (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
+                for (int ch = sA + ((part - sA) & (P - 1)); ch < sB; ch += P) {
+                    const uint32_t b0 = bo[ch], b1 = bo[ch + 1];
+                    double cs = 0.0;
+                    for (uint32_t b = b0; b < b1; ++b) {
+                        const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
+                        const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
+                        cs += masked_weight(my_row, e0);
+                        cs += masked_weight(my_row, e1);
+                        cs += masked_weight(my_row, e2);
+                        cs += masked_weight(my_row, e3);
+                    }
+                    z += cs;
                 }
             }
-#else
-            if (active) z0 += (double)my_row[ch];
-#endif
         }
-        double z = (z0 + z1) + (z2 + z3);
-        if (P > 1) {  // workgroup-uniform: combine the P partial sums of each sibling in a fixed order
+        if (active) z = add_outside(z, cg, wB, a.NC, part, P);
+        if (P > 1) {  // workgroup-uniform: combine the P class sums of each sibling in a fixed order
             s_z[wave][lane] = z;
             __syncthreads();
             if (active && part == 0) {
@@ -524,185 +571,6 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         } else {
             a.node[seq] = -1;  // every probability was NaN: the reference stops here (classify.py:49)
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// walk, one-chunk rows (L <= 7,680): persistent workgroups + windowed staging.
-// Same arithmetic as k_walk_level.  Differences: (1) a workgroup loops over tasks, so its LDS
-// rows keep the all-gaps row R0 everywhere except the current task's window; only the window
-// (the union of the 64 rows' windows, see r0_word) is read from HBM: for 253-column amplicon
-// reads in a 1,500-column alignment that is 168 B per row instead of 944 B; (2) the next
-// task's window is fetched into registers before the current task is scored, so the loads
-// overlap the scoring.
-// ------------------------------------------------------------------------------------------
-constexpr int ROWS_PER_WAVE = TILE / NW;
-
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return __builtin_amdgcn_readfirstlane(v);
-}
-
-__global__ __launch_bounds__(NW * 64) void k_walk_level_win(WalkArgs a) {
-    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
-    __shared__ uint32_t s_pat[CHUNK_WORDS];
-    __shared__ double s_z[NW][TILE];
-    __shared__ int s_c[NW][TILE];
-
-    const int n_tasks = *as_const(a.n_tasks);
-    const int32_t STAG_CONST *child_first = as_const(a.child_first);
-    const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
-    const u32x4 STAG_CONST *blocks = as_const(reinterpret_cast<const u32x4 *>(a.blocks));
-    const i32x4 STAG_CONST *tasks = as_const(reinterpret_cast<const i32x4 *>(a.tasks));
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const char *my_row = reinterpret_cast<const char *>(s_rows + lane * ROW_STRIDE);
-
-    for (int w = threadIdx.x; w < CHUNK_WORDS; w += NW * 64) s_pat[w] = w < a.W ? a.pat[w] : 0u;
-    for (int rr = 0; rr < ROWS_PER_WAVE; ++rr)
-        for (int w = lane; w < CHUNK_WORDS; w += 64) s_rows[(rr * NW + wave) * ROW_STRIDE + w] = w < a.W ? a.pat[w] : 0u;
-
-    // ---- prefetch state of the NEXT task
-    int seq_n = -1, A_n = 0, Wd_n = 0, node_n = 0, k_n = 0;
-    uint32_t v[ROWS_PER_WAVE][4];
-    auto prefetch = [&](int task) {
-        const i32x4 tk = tasks[task];
-        node_n = tk.x;
-        seq_n = lane < tk.z ? a.order[tk.y + lane] : -1;
-        k_n = child_first[node_n + 1] - child_first[node_n];
-        A_n = 0;
-        Wd_n = 0;
-        if (k_n < 2 || a.node_err[node_n]) return;   // nothing is scored: no rows needed
-        int lo = 0xffff, hi = 0;
-        if (seq_n >= 0) {
-            const uint32_t wn = a.win ? a.win[seq_n] : ((uint32_t)(a.W >> 2) << 16);
-            lo = (int)(wn & 0xffffu);
-            hi = (int)(wn >> 16);
-            if (hi <= lo) { lo = 0xffff; hi = 0; }
-        }
-        lo = wave_min_i(lo);
-        hi = wave_max_i(hi);
-        if (hi <= lo) return;                          // every row equals R0
-        A_n = 4 * lo;
-        Wd_n = min(4 * (hi - lo), a.W - A_n);
-#pragma unroll
-        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-            const int s = __shfl(seq_n, rr * NW + wave);  // wave-uniform
-            const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + A_n;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int w = lane + 64 * i;
-                v[rr][i] = (s >= 0 && w < Wd_n) ? src[w] : 0u;
-            }
-        }
-    };
-
-    int task = blockIdx.x;
-    if (task < n_tasks) prefetch(task);
-    while (task < n_tasks) {
-        const int seq = seq_n, A = A_n, Wd = Wd_n, node = node_n, k = k_n;
-        const int c0 = child_first[node];
-        // ---- window of this task: registers -> LDS (rows beyond the task's count stay R0)
-#pragma unroll
-        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-            const int s = __shfl(seq, rr * NW + wave);
-            uint32_t *d = s_rows + (rr * NW + wave) * ROW_STRIDE + A;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (s >= 0 && lane + 64 * i < Wd) d[lane + 64 * i] = v[rr][i];
-        }
-        __syncthreads();
-        const int next = task + gridDim.x;
-        if (next < n_tasks) prefetch(next);   // its loads are in flight while this task is scored
-
-        if (k == 1 || a.node_err[node]) {
-            if (wave == 0 && seq >= 0) {
-                if (k == 1) {
-                    a.path_node[(size_t)seq * a.D + a.depth] = c0;
-                    a.path_prob[(size_t)seq * a.D + a.depth] = 2.0;
-                    a.path_len[seq] = a.depth + 1;
-                    a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
-                } else {
-                    a.status[seq] = a.node_err[node];
-                    a.node[seq] = -1;
-                }
-            }
-        } else {
-            double best_p = -1.0;
-            int best_c = -1;
-            for (int pass0 = 0; pass0 < k; pass0 += NW) {
-                const int kk = min(NW, k - pass0);
-                const int P = NW / kk;
-                const int ci = wave / P, part = wave - ci * P;
-                const bool active = ci < kk;
-                const int c = c0 + pass0 + ci;
-                double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
-                if (active) {
-                    const uint32_t b0 = blk_off[c], b1 = blk_off[c + 1];
-                    for (uint32_t b = b0 + part; b < b1; b += P) {
-                        const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
-                        const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3], e4 = e[4], e5 = e[5], e6 = e[6], e7 = e[7];
-                        z0 += masked_weight(my_row, e0);
-                        z1 += masked_weight(my_row, e1);
-                        z2 += masked_weight(my_row, e2);
-                        z3 += masked_weight(my_row, e3);
-                        z0 += masked_weight(my_row, e4);
-                        z1 += masked_weight(my_row, e5);
-                        z2 += masked_weight(my_row, e6);
-                        z3 += masked_weight(my_row, e7);
-                    }
-                }
-                double z = (z0 + z1) + (z2 + z3);
-                if (P > 1) {
-                    s_z[wave][lane] = z;
-                    __syncthreads();
-                    if (active && part == 0) {
-                        z = 0.0;
-                        for (int j = 0; j < P; ++j) z += s_z[wave + j][lane];
-                    }
-                    __syncthreads();
-                }
-                if (active && part == 0) {
-                    const double p = sigmoid(z + as_const(a.intercept)[c]);
-                    if (p > best_p) { best_p = p; best_c = c; }
-                }
-            }
-            s_z[wave][lane] = best_p;
-            s_c[wave][lane] = best_c;
-            __syncthreads();
-            if (wave == 0 && seq >= 0) {
-                for (int w = 1; w < NW; ++w) {
-                    const double p = s_z[w][lane];
-                    const int cc = s_c[w][lane];
-                    if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
-                }
-                if (best_c >= 0) {
-                    a.path_node[(size_t)seq * a.D + a.depth] = best_c;
-                    a.path_prob[(size_t)seq * a.D + a.depth] = best_p;
-                    a.path_len[seq] = a.depth + 1;
-                    a.node[seq] = a.child_first[best_c + 1] > a.child_first[best_c] ? best_c : -1;
-                } else {
-                    a.node[seq] = -1;
-                }
-            }
-        }
-        __syncthreads();   // every wave is done with the rows (and with s_z / s_c)
-        // ---- put R0 back into the window (each wave restores the rows it wrote)
-#pragma unroll
-        for (int rr = 0; rr < ROWS_PER_WAVE; ++rr) {
-            const int s = __shfl(seq, rr * NW + wave);
-            uint32_t *d = s_rows + (rr * NW + wave) * ROW_STRIDE + A;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (s >= 0 && lane + 64 * i < Wd) d[lane + 64 * i] = s_pat[A + lane + 64 * i];
-        }
-        task = next;
     }
 }
 
