@@ -266,7 +266,11 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     }
     {
         Prof p(db, st, 3);
-        hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), 0, st, n, D, db->n_keys, db->n_tf, db->tf.p, o.path_len,
+        const size_t lds = (size_t)256 * (D + db->n_keys) * sizeof(double);
+        if (lds > 160 * 1024) return fail(STAG_E_INVALID, "tree depth %d + %d rank-cut keys exceed the rank-cut kernel's LDS tile", D, db->n_keys);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_rankcut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), lds, st, n, D, db->n_keys, db->n_tf, db->tf.p, o.path_len,
                            o.path_prob, o.lead, o.level_prob, o.selected, o.status);
     }
     return launch_check("k_rankcut");

@@ -21,9 +21,9 @@
 namespace stagk {
 
 constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
-constexpr int NW = 8;             // waves per walk workgroup (all share the 64 staged rows)
+constexpr int NW = 4;             // waves per walk workgroup (all share the 64 staged rows)
 constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-byte sector of a row)
-constexpr int WCAP_CHUNKS = 5;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
+constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
 constexpr int BLOCK_ENTRIES = 4;  // entries per scalar fetch (one s_load_dwordx16)
 
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void k_init_walk(int64_t n, int D, const int32
 //  * levels with <= ASSIGN_BINS nodes: LDS histogram over the level's node range, then one
 //    global atomic per (workgroup, non-empty bin);
 //  * wider levels: per-wave grouping by ballot (ALU only), then one atomic per (wave, node).
-constexpr int ASSIGN_BINS = 4096;
+constexpr int ASSIGN_BINS = 15360;   // 60 KB of LDS counters
 constexpr int ASSIGN_THREADS = 1024;
 
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, int hi,
@@ -577,57 +577,71 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
 // ------------------------------------------------------------------------------------------
 // rank cut: classify.py:106-110 (placeholder fix-up) and :58-72 (find_correct_level)
 // ------------------------------------------------------------------------------------------
+// One workgroup = 256 sequences.  Their path probabilities ([256][D] doubles, contiguous in
+// HBM) are moved through LDS with coalesced loads/stores; each thread then works on its own
+// D values in LDS (a thread touching its own 56-byte slice of HBM costs one cache line per lane).
 __global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int K, int n_tf, const double *__restrict__ tf,
                                                  const int32_t *__restrict__ path_len, double *__restrict__ path_prob,
                                                  int32_t *__restrict__ n_lead_single, double *__restrict__ level_prob,
                                                  int32_t *__restrict__ selected, int32_t *__restrict__ status) {
-    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    int sel = -1, lead = 0;
-    int st = status[s];
-    const int len = path_len[s];
-    double *pp = path_prob + (size_t)s * D;
-    double *lp = level_prob + (size_t)s * K;
-    for (int kk = 0; kk < K; ++kk) lp[kk] = 0.0;
-    if (st == 0 && len == 0) st = 4;  // perc[0] on an empty list
-    if (st == 0) {
-        bool leading = true;
-        for (int i = 0; i < len; ++i) {
-            double p = pp[i];
-            if (p == 2.0) {
-                p = i == 0 ? 1.0 : pp[i - 1];
-                pp[i] = p;
-                if (leading) ++lead;
-            } else {
-                leading = false;
+    extern __shared__ double s_rc[];   // [256][D] path probabilities, then [256][K] level probabilities
+    const int64_t s0 = (int64_t)blockIdx.x * 256;
+    const int cnt = (int)min((int64_t)256, n - s0);
+    double *s_pp = s_rc, *s_lp = s_rc + 256 * D;
+    for (int i = threadIdx.x; i < cnt * D; i += 256) s_pp[i] = path_prob[(size_t)s0 * D + i];
+    __syncthreads();
+    const int64_t s = s0 + threadIdx.x;
+    if (threadIdx.x < cnt) {
+        int sel = -1, lead = 0;
+        int st = status[s];
+        const int len = path_len[s];
+        double *pp = s_pp + threadIdx.x * D;
+        double *lp = s_lp + threadIdx.x * K;
+        const double STAG_CONST *tfc = as_const(tf);
+        for (int kk = 0; kk < K; ++kk) lp[kk] = 0.0;
+        if (st == 0 && len == 0) st = 4;  // perc[0] on an empty list
+        if (st == 0) {
+            bool leading = true;
+            for (int i = 0; i < len; ++i) {
+                double p = pp[i];
+                if (p == 2.0) {
+                    p = i == 0 ? 1.0 : pp[i - 1];
+                    pp[i] = p;
+                    if (leading) ++lead;
+                } else {
+                    leading = false;
+                }
             }
-        }
-        for (int i = len; i < D; ++i) pp[i] = 0.0;
-        double best = 0.0;
-        for (int kk = 0; kk < K; ++kk) {
-            const double *row = tf + (size_t)kk * (1 + n_tf);
-            double acc = 0.0;
-            if (len == n_tf) {
-                for (int i = 0; i < len; ++i) acc += row[1 + i] * pp[i];
-            } else if (len == 1) {
-                for (int i = 0; i < n_tf; ++i) acc += row[1 + i] * pp[0];
-            } else if (n_tf == 1) {
-                for (int i = 0; i < len; ++i) acc += row[1] * pp[i];
-            } else {
-                st = 3;
-                break;
+            for (int i = len; i < D; ++i) pp[i] = 0.0;
+            double best = 0.0;
+            for (int kk = 0; kk < K; ++kk) {
+                const double STAG_CONST *row = tfc + (size_t)kk * (1 + n_tf);
+                double acc = 0.0;
+                if (len == n_tf) {
+                    for (int i = 0; i < len; ++i) acc += row[1 + i] * pp[i];
+                } else if (len == 1) {
+                    for (int i = 0; i < n_tf; ++i) acc += row[1 + i] * pp[0];
+                } else if (n_tf == 1) {
+                    for (int i = 0; i < len; ++i) acc += row[1] * pp[i];
+                } else {
+                    st = 3;
+                    break;
+                }
+                const double p = sigmoid(acc + row[0]);
+                lp[kk] = p;
+                if (p > best) { best = p; sel = kk; }
             }
-            const double p = sigmoid(acc + row[0]);
-            lp[kk] = p;
-            if (p > best) { best = p; sel = kk; }
+            if (st != 0) sel = -1;
+        } else {
+            for (int i = 0; i < D; ++i) pp[i] = 0.0;
         }
-        if (st != 0) sel = -1;
-    } else {
-        for (int i = 0; i < D; ++i) pp[i] = 0.0;
+        n_lead_single[s] = lead;
+        selected[s] = sel;
+        status[s] = st;
     }
-    n_lead_single[s] = lead;
-    selected[s] = sel;
-    status[s] = st;
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt * D; i += 256) path_prob[(size_t)s0 * D + i] = s_pp[i];
+    for (int i = threadIdx.x; i < cnt * K; i += 256) level_prob[(size_t)s0 * K + i] = s_lp[i];
 }
 
 }  // namespace stagk
