@@ -25,7 +25,9 @@ constexpr int NW = 4;             // waves per walk workgroup (all share the 64 
 constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-byte sector of a row)
 constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
-constexpr int BLOCK_ENTRIES = 4;  // entries per scalar fetch (one s_load_dwordx16)
+constexpr int BLOCK_ENTRIES = 4;  // coefficient lists are padded to 4 entries per (row, chunk)
+static_assert(WCAP_CHUNKS * CHUNK_WORDS <= 64, "a staged slice is one dword per lane and row");
+constexpr int ENT_PIECE = 64;     // coefficients a wave keeps in LDS at a time (one 16-byte load per lane)
 
 struct Entry {      // 16 bytes
     uint32_t off;   // byte offset of the feature's word inside the row
@@ -422,19 +424,39 @@ __device__ __forceinline__ double add_outside(double z, const double STAG_CONST 
     return z;
 }
 
+// 64-lane min / max with DPP moves (no LDS traffic); the result is wave-uniform.
 __device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = min(v, __shfl_xor(v, d));
-    return __builtin_amdgcn_readfirstlane(v);
+    const int I = 0x7fffffff;
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v = min(v, __builtin_amdgcn_update_dpp(I, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
 }
 __device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d));
-    return __builtin_amdgcn_readfirstlane(v);
+    const int I = (int)0x80000000;
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x111, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x112, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x114, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x118, 0xf, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x142, 0xa, 0xf, false));
+    v = max(v, __builtin_amdgcn_update_dpp(I, v, 0x143, 0xc, 0xf, false));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// entry en = {off, bit, w_lo, w_hi} in VGPRs (same value in every lane): w if this lane's row
+// has the feature, else +0.0
+__device__ __forceinline__ double masked_weight_v(const char *my_row, const uint4 en) {
+    const uint32_t x = *reinterpret_cast<const uint32_t *>(my_row + en.x);
+    const int m = __builtin_amdgcn_sbfe((int)x, en.y, 1u);  // 0 or -1
+    return __hiloint2double((int)en.w & m, (int)en.z & m);
 }
 
 __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
     __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
+    __shared__ uint4 s_ent[NW][ENT_PIECE];   // per wave: the coefficients of its sibling inside the slice
     __shared__ double s_z[NW][TILE];
     __shared__ int s_c[NW][TILE];
 
@@ -442,7 +464,6 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
     const i32x4 tk = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];  // node, start, count
     const int32_t STAG_CONST *child_first = as_const(a.child_first);
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
-    const u32x4 STAG_CONST *blocks = as_const(reinterpret_cast<const u32x4 *>(a.blocks));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int node = tk.x;
@@ -502,38 +523,47 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         if (active) z = add_outside(z, cg, 0, wA, part, P);
         for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
             const int sB = min(wB, sA + WCAP_CHUNKS);
+            // this wave's coefficient range of the slice: contiguous, chunk after chunk
+            uint32_t e_lo = 0, e_hi = 0;
+            if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
+            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
+            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+            if (piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
             if (!one_slice || pass0 == 0) {
                 const int w0 = sA * CHUNK_WORDS;
-                const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= 80 words
-                __syncthreads();  // everyone is done reading the previous slice
-                // one row per wave and step, lanes over consecutive words: coalesced loads and
-                // LDS stores on 32 different banks
+                const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
+                uint32_t v[TILE / NW];
 #pragma unroll
-                for (int rr = 0; rr < TILE / NW; ++rr) {
-                    const int r = rr * NW + wave;
-                    const int s = __shfl(seq, r);  // wave-uniform
-                    const uint32_t *src = a.bits + (size_t)(s < 0 ? 0 : s) * a.W + w0;
-                    const uint32_t v0 = (s >= 0 && lane < width) ? src[lane] : 0u;
-                    const uint32_t v1 = (s >= 0 && lane + 64 < width) ? src[lane + 64] : 0u;
-                    s_rows[r * ROW_STRIDE + lane] = v0;
-                    if (lane + 64 < ROW_STRIDE - 1) s_rows[r * ROW_STRIDE + lane + 64] = v1;
+                for (int rr = 0; rr < TILE / NW; ++rr) {   // one row per wave and step, lanes over words
+                    const int s = __shfl(seq, rr * NW + wave);  // wave-uniform
+                    v[rr] = (s >= 0 && lane < width) ? a.bits[(size_t)s * a.W + w0 + lane] : 0u;
                 }
+                __syncthreads();  // everyone is done reading the previous slice
+#pragma unroll
+                for (int rr = 0; rr < TILE / NW; ++rr) s_rows[(rr * NW + wave) * ROW_STRIDE + lane] = v[rr];
+                s_ent[wave][lane] = ent;
                 __syncthreads();
+            } else {
+                s_ent[wave][lane] = ent;   // wave-private: LDS operations of one wave stay in order
             }
             if (active) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
                                      (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
                 for (int ch = sA + ((part - sA) & (P - 1)); ch < sB; ch += P) {
-                    const uint32_t b0 = bo[ch], b1 = bo[ch + 1];
+                    const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
                     double cs = 0.0;
-                    for (uint32_t b = b0; b < b1; ++b) {
-                        const u32x4 STAG_CONST *e = blocks + (size_t)b * BLOCK_ENTRIES;
-                        const u32x4 e0 = e[0], e1 = e[1], e2 = e[2], e3 = e[3];
-                        cs += masked_weight(my_row, e0);
-                        cs += masked_weight(my_row, e1);
-                        cs += masked_weight(my_row, e2);
-                        cs += masked_weight(my_row, e3);
+                    for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                        if (e >= piece + ENT_PIECE) {   // rare: more than 64 coefficients in the slice
+                            piece = e;
+                            s_ent[wave][lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
+                        }
+                        const uint4 *pe = &s_ent[wave][e - piece];   // wave-uniform address: LDS broadcast
+                        const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                        cs += masked_weight_v(my_row, n0);
+                        cs += masked_weight_v(my_row, n1);
+                        cs += masked_weight_v(my_row, n2);
+                        cs += masked_weight_v(my_row, n3);
                     }
                     z += cs;
                 }
