@@ -79,7 +79,8 @@ struct stag_db {
     DevBuf<double> tf;
     // workspace (grown by reserve)
     int64_t cap_n = 0;
-    DevBuf<int32_t> node, pos, order, count, node_off, task_off, n_tasks;
+    DevBuf<int32_t> node, pos, count, node_off, task_off, n_tasks;
+    DevBuf<SeqRef> order;
     DevBuf<Task> tasks;
     DevBuf<uint32_t> bits, win;
     DevBuf<double> chunkgap;
@@ -247,16 +248,16 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
             hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->node_off.p,
                                db->task_off.p, db->n_tasks.p + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, db->node.p, db->pos.p, db->count.p,
-                               db->node_off.p, db->task_off.p, db->order.p, db->tasks.p);
+                               db->node_off.p, db->task_off.p, db->child_first.p, db->node_err.p, db->win.p, db->order.p, db->tasks.p);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
         a.bits = d_bits; a.W = db->W; a.NC = db->nchunks; a.depth = d; a.D = D;
         a.n_tasks = db->n_tasks.p + d; a.tasks = db->tasks.p; a.order = db->order.p;
-        a.child_first = db->child_first.p; a.node_err = db->node_err.p; a.intercept = db->intercept.p;
+        a.child_first = db->child_first.p; a.intercept = db->intercept.p;
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p; a.node = db->node.p;
         a.path_node = o.path_node; a.path_prob = o.path_prob; a.path_len = o.path_len; a.status = o.status;
-        a.win = db->win.p; a.chunkgap = db->chunkgap.p;
+        a.chunkgap = db->chunkgap.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
             Prof p(db, st, 1);

@@ -27,7 +27,6 @@ constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
 constexpr int BLOCK_ENTRIES = 4;  // coefficient lists are padded to 4 entries per (row, chunk)
 static_assert(WCAP_CHUNKS * CHUNK_WORDS <= 64, "a staged slice is one dword per lane and row");
-constexpr int ENT_PIECE = 64;     // coefficients a wave keeps in LDS at a time (one 16-byte load per lane)
 
 struct Entry {      // 16 bytes
     uint32_t off;   // byte offset of the feature's word inside the row
@@ -43,12 +42,18 @@ __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
     return (const T STAG_CONST *)(uintptr_t)p;
 }
 
-struct Task {
-    int32_t node, start, count, pad;
+struct Task {       // 32 bytes: one s_load_dwordx8 tells a workgroup everything about its task
+    int32_t node, start, count, err;   // err: status every sequence reaching this node gets (0 = fine)
+    int32_t c0, k, pad0, pad1;         // children of node: ids c0 .. c0+k-1
+};
+struct SeqRef {     // order[]: a sequence id and its R0 window, so the walk needs one load, not two
+    int32_t seq;
+    uint32_t win;
 };
 // plain vector types: unlike HIP's uint4 class they can be loaded from the constant address space
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
 using i32x4 = __attribute__((ext_vector_type(4))) int32_t;
+using i32x8 = __attribute__((ext_vector_type(8))) int32_t;
 
 // ------------------------------------------------------------------------------------------
 // encode: stag/align.py:28-58 (+ the filter of :160).  One wave per aligned string.
@@ -346,18 +351,24 @@ __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ count,
                                                  const int32_t *__restrict__ node_off,
-                                                 const int32_t *__restrict__ task_off, int32_t *__restrict__ order,
-                                                 Task *__restrict__ tasks) {
+                                                 const int32_t *__restrict__ task_off,
+                                                 const int32_t *__restrict__ child_first,
+                                                 const uint8_t *__restrict__ node_err, const uint32_t *__restrict__ win,
+                                                 SeqRef *__restrict__ order, Task *__restrict__ tasks) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int nd = node[s];
     if (nd < lo || nd >= hi) return;
     const int p = pos[s];
     const int at = node_off[nd] + p;
-    order[at] = (int32_t)s;
+    SeqRef ref;
+    ref.seq = (int32_t)s;
+    ref.win = win[s];
+    order[at] = ref;
     if ((p & (TILE - 1)) == 0) {
         Task tk;
-        tk.node = nd; tk.start = at; tk.count = min(TILE, count[nd] - p); tk.pad = 0;
+        tk.node = nd; tk.start = at; tk.count = min(TILE, count[nd] - p); tk.err = node_err[nd];
+        tk.c0 = child_first[nd]; tk.k = child_first[nd + 1] - tk.c0; tk.pad0 = 0; tk.pad1 = 0;
         tasks[task_off[nd] + p / TILE] = tk;
     }
 }
@@ -384,9 +395,8 @@ struct WalkArgs {
     int W, NC, depth, D;        // NC = chunks per row
     const int32_t *n_tasks;
     const Task *tasks;
-    const int32_t *order;
+    const SeqRef *order;
     const int32_t *child_first;
-    const uint8_t *node_err;    // per parent: status every sequence reaching it gets (0 = fine)
     const double *intercept;
     const uint32_t *blk_off;    // [n_nodes*NC + 1]
     const double *chunkgap;     // [n_nodes][NC] (+8 padding): sum of a chunk's coefficients on "others" bits
@@ -396,7 +406,6 @@ struct WalkArgs {
     double *path_prob;          // [n][D]  (2.0 = "single child" placeholder, classify.py:37)
     int32_t *path_len;
     int32_t *status;
-    const uint32_t *win;        // [n] R0 window of each row (lo4 | hi4 << 16, units of 4 words)
 };
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
@@ -454,24 +463,34 @@ __device__ __forceinline__ double masked_weight_v(const char *my_row, const uint
     return __hiloint2double((int)en.w & m, (int)en.z & m);
 }
 
-__global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
-    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
-    __shared__ uint4 s_ent[NW][ENT_PIECE];   // per wave: the coefficients of its sibling inside the slice
-    __shared__ double s_z[NW][TILE];
-    __shared__ int s_c[NW][TILE];
+constexpr int ENT_PIECE = 48;     // coefficients a wave keeps in LDS at a time (768 B)
 
-    if ((int)blockIdx.x >= *as_const(a.n_tasks)) return;
-    const i32x4 tk = as_const(reinterpret_cast<const i32x4 *>(a.tasks))[blockIdx.x];  // node, start, count
+__global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
+    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
+    // per wave 768 B: the coefficients of its sibling inside the slice while it scores, then its
+    // result slot (64 doubles + 64 ints) for the combine steps
+    __shared__ uint4 s_buf[NW][ENT_PIECE];
+    static_assert(ENT_PIECE * 16 >= TILE * 12, "result slot must fit the coefficient buffer");
+
+    const int n_tasks = *as_const(a.n_tasks);
+    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[blockIdx.x];
+    if ((int)blockIdx.x >= n_tasks) return;
     const int32_t STAG_CONST *child_first = as_const(a.child_first);
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node = tk.x;
-    const int seq = lane < tk.z ? a.order[tk.y + lane] : -1;
-    const int c0 = child_first[node];
-    const int k = child_first[node + 1] - c0;
+    const int node = tk[0], err = tk[3], c0 = tk[4], k = tk[5];
+    (void)node;
+    SeqRef me;
+    me.seq = -1;
+    me.win = 0xffffu;
+    if (lane < tk[2]) me = a.order[tk[1] + lane];
+    const int seq = me.seq;
+    uint4 *s_ent = s_buf[wave];
+    auto s_z = [&](int w) { return reinterpret_cast<double *>(s_buf[w]); };
+    auto s_c = [&](int w) { return reinterpret_cast<int *>(s_buf[w]) + 2 * TILE; };
 
-    if (k == 1 || a.node_err[node]) {  // nothing to score (classify.py:35-37) or the reference raises
+    if (k == 1 || err) {  // nothing to score (classify.py:35-37) or the reference raises
         if (wave == 0 && seq >= 0) {
             if (k == 1) {
                 a.path_node[(size_t)seq * a.D + a.depth] = c0;
@@ -479,7 +498,7 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
                 a.path_len[seq] = a.depth + 1;
                 a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
             } else {
-                a.status[seq] = a.node_err[node];
+                a.status[seq] = err;
                 a.node[seq] = -1;
             }
         }
@@ -489,7 +508,7 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
     // ---- the task's window in chunks [cA, cB): union of its rows' windows
     int lo = 0x7fff, hi = 0;
     if (seq >= 0) {
-        const uint32_t wn = a.win[seq];
+        const uint32_t wn = me.win;
         const int l4 = (int)(wn & 0xffffu), h4 = (int)(wn >> 16);
         if (h4 > l4) { lo = l4 >> 2; hi = (h4 + 3) >> 2; }   // 4-word units -> 16-word chunks
     }
@@ -528,7 +547,7 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
             if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
             uint32_t piece = e_lo;   // first entry held in s_ent[wave]
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-            if (piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
+            if (lane < ENT_PIECE && piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
             if (!one_slice || pass0 == 0) {
                 const int w0 = sA * CHUNK_WORDS;
                 const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
@@ -541,10 +560,10 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
                 __syncthreads();  // everyone is done reading the previous slice
 #pragma unroll
                 for (int rr = 0; rr < TILE / NW; ++rr) s_rows[(rr * NW + wave) * ROW_STRIDE + lane] = v[rr];
-                s_ent[wave][lane] = ent;
+                if (lane < ENT_PIECE) s_ent[lane] = ent;
                 __syncthreads();
             } else {
-                s_ent[wave][lane] = ent;   // wave-private: LDS operations of one wave stay in order
+                if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private: LDS operations of one wave stay in order
             }
             if (active) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
@@ -554,11 +573,12 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
                     const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
                     double cs = 0.0;
                     for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                        if (e >= piece + ENT_PIECE) {   // rare: more than 64 coefficients in the slice
+                        if (e >= piece + ENT_PIECE) {   // rare: more than 48 coefficients in the slice
                             piece = e;
-                            s_ent[wave][lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
+                            if (lane < ENT_PIECE)
+                                s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
                         }
-                        const uint4 *pe = &s_ent[wave][e - piece];   // wave-uniform address: LDS broadcast
+                        const uint4 *pe = &s_ent[e - piece];   // wave-uniform address: LDS broadcast
                         const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
                         cs += masked_weight_v(my_row, n0);
                         cs += masked_weight_v(my_row, n1);
@@ -571,11 +591,11 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
         }
         if (active) z = add_outside(z, cg, wB, a.NC, part, P);
         if (P > 1) {  // workgroup-uniform: combine the P class sums of each sibling in a fixed order
-            s_z[wave][lane] = z;
+            s_z(wave)[lane] = z;
             __syncthreads();
             if (active && part == 0) {
                 z = 0.0;
-                for (int j = 0; j < P; ++j) z += s_z[wave + j][lane];
+                for (int j = 0; j < P; ++j) z += s_z(wave + j)[lane];
             }
             __syncthreads();
         }
@@ -584,13 +604,13 @@ __global__ __launch_bounds__(NW * 64) void k_walk_level(WalkArgs a) {
             if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
         }
     }
-    s_z[wave][lane] = best_p;
-    s_c[wave][lane] = best_c;
+    s_z(wave)[lane] = best_p;
+    s_c(wave)[lane] = best_c;
     __syncthreads();
     if (wave == 0 && seq >= 0) {
         for (int w = 1; w < NW; ++w) {  // first maximum in stored order = largest p, then smallest id
-            const double p = s_z[w][lane];
-            const int cc = s_c[w][lane];
+            const double p = s_z(w)[lane];
+            const int cc = s_c(w)[lane];
             if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
         }
         if (best_c >= 0) {
