@@ -150,21 +150,36 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
                uint32_t *d_win, hipStream_t st) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
-    const size_t lds = (size_t)4 * W * sizeof(uint32_t);
-    if (lds > 160 * 1024) return fail(STAG_E_INVALID, "n_features %d too large for the encode kernel's LDS row buffers", L);
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
         return fail(STAG_E_INVALID, "d_text and d_bits must be 16-byte aligned");
     if (text_bytes & 15)
         return fail(STAG_E_INVALID, "text_bytes (the size of the text buffer) must be a multiple of 16: pad the buffer");
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)k_encode_a2m, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t grid = (n + 3) / 4;
-    if (grid > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
-    {
-        Prof p(db_for_prof, st, 0);
-        hipLaunchKernelGGL(k_encode_a2m, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
-                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win);
+    // lanes per record: the candidate that wastes the fewest lane slots on an average record
+    // (ties go to the wider group: fewer, longer-lived rows in LDS)
+    const int64_t avg = std::max<int64_t>(1, text_bytes / n);
+    int G = 64;
+    int64_t best_slots = -1;
+    for (int g : {64, 32, 16}) {
+        const int64_t slots = ((avg + 16 * g - 1) / (16 * g)) * g;
+        const size_t need = (size_t)4 * (64 / g) * W * sizeof(uint32_t);
+        if (need > 160 * 1024) continue;
+        if (best_slots < 0 || slots < best_slots) { best_slots = slots; G = g; }
     }
+    if (best_slots < 0) return fail(STAG_E_INVALID, "n_features %d too large for the encode kernel's LDS row buffers", L);
+    const int rpw = 64 / G;
+    const size_t lds = (size_t)4 * rpw * W * sizeof(uint32_t);
+    const int64_t grid = (n + 4 * rpw - 1) / (4 * rpw);
+    if (grid > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    auto launch = [&](auto kernel) -> int {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        Prof p(db_for_prof, st, 0);
+        hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
+                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win);
+        return STAG_OK;
+    };
+    int rc = G == 64 ? launch(k_encode_a2m<64>) : G == 32 ? launch(k_encode_a2m<32>) : launch(k_encode_a2m<16>);
+    if (rc) return rc;
     return launch_check("k_encode_a2m");
 }
 

@@ -90,6 +90,10 @@ __device__ __forceinline__ uint32_t r0_word(int w, int L) {
     return v;
 }
 
+// G = lanes per record (16, 32 or 64): a wave encodes 64/G records side by side, each lane
+// taking 16 bytes of its record per step.  The host picks G so that a record's length wastes few
+// lane slots (a 1,501-byte record is 2 steps of 64 lanes = 2,048 slots, or 3 steps of 32 = 1,536).
+template <int G>
 __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ text, int64_t text_bytes,
                                                     const int64_t *__restrict__ offs, int64_t n, int L, int W,
                                                     double min_perc, uint32_t *__restrict__ rows,
@@ -97,15 +101,18 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ n_aligned_out,
                                                     int32_t *__restrict__ status_out,
                                                     uint32_t *__restrict__ win_out) {
-    extern __shared__ uint32_t s_enc[];  // 4 waves x W words
+    extern __shared__ uint32_t s_enc[];  // one W-word row per record of the workgroup
+    constexpr int RPW = 64 / G;          // records per wave
     const int lane = threadIdx.x & 63;
+    const int gl = lane & (G - 1);       // lane inside the record's group
+    const int grp = lane / G;
     const int wave = threadIdx.x >> 6;
-    const int64_t seq = (int64_t)blockIdx.x * 4 + wave;
-    if (seq >= n) return;  // whole wave leaves; no workgroup barrier below
-    uint32_t *row = s_enc + (size_t)wave * W;
-    for (int w = lane; w < W; w += 64) row[w] = 0;
+    const int64_t seq = ((int64_t)blockIdx.x * 4 + wave) * RPW + grp;
+    const bool live = seq < n;
+    uint32_t *row = s_enc + (size_t)(wave * RPW + grp) * W;
+    for (int w = gl; w < W; w += G) row[w] = 0;
 
-    const int64_t begin = offs[seq], end = offs[seq + 1];
+    const int64_t begin = live ? offs[seq] : 0, end = live ? offs[seq + 1] : 0;
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
     // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
@@ -116,11 +123,11 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     };
     uint32_t nxt[4];
-    load16(base + (int64_t)lane * 16, nxt);
-    for (int64_t p0 = base; p0 < end; p0 += 1024) {
-        const int64_t p = p0 + (int64_t)lane * 16;
+    load16(base + (int64_t)gl * 16, nxt);
+    for (int64_t p0 = base; __ballot(p0 < end) != 0ull; p0 += 16 * G) {
+        const int64_t p = p0 + (int64_t)gl * 16;
         uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
-        load16(p + 1024, nxt);   // the next vector is in flight while this one is encoded
+        load16(p + 16 * G, nxt);   // the next vector is in flight while this one is encoded
         // bytes outside [begin, end) (first and last vector of a record) become '\n' = skipped
         if (p < begin || p + 16 > end) {
             const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
@@ -134,10 +141,8 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                 wv[j] = (wv[j] & keep) | (0x0a0a0a0au & ~keep);
             }
         }
-        // Branch-free SWAR over the 4 dwords: classify 4 bytes at a time, pack the kept bytes'
-        // 5-bit one-hot groups densely (a skipped byte contributes no group).
-        uint32_t pk[4];
-        int cnt[4];
+        // Branch-free SWAR over the 4 dwords: classify 4 bytes at a time.
+        uint32_t code[4], skip80[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t x = wv[j];
@@ -145,7 +150,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             // skipped: 'a'..'z' (HMM insert states, align.py:47) and 0x0a..0x0d (line breaks)
             const uint32_t ge61 = t + 0x1f1f1f1fu, ge7b = t + 0x05050505u;
             const uint32_t ge0a = t + 0x76767676u, ge0e = t + 0x72727272u;
-            const uint32_t skip80 = ((ge61 & ~ge7b) | (ge0a & ~ge0e)) & ~x & 0x80808080u;
+            skip80[j] = ((ge61 & ~ge7b) | (ge0a & ~ge0e)) & ~x & 0x80808080u;
             // A/C/G/T/U differ in their low 3 bits (1,3,7,4,5): two byte-LUTs indexed by them give
             // the character that index stands for and its one-hot group; any other byte is "others"
             const uint32_t sel = x & 0x07070707u;
@@ -154,24 +159,53 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             const uint32_t y = x ^ expc;
             const uint32_t eq80 = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;  // byte == expected
             const uint32_t eqm = (eq80 >> 7) * 0xffu;
-            uint32_t code = (oneh & eqm) | (0x01010101u & ~eqm);
-            code &= ~((skip80 >> 7) * 0xffu);
+            code[j] = (oneh & eqm) | (0x01010101u & ~eqm);
             aligned += __popc(eq80);
-            const uint32_t k0 = ((skip80 >> 7) & 1u) ^ 1u, k1 = ((skip80 >> 15) & 1u) ^ 1u;
-            const uint32_t k2 = ((skip80 >> 23) & 1u) ^ 1u, k3 = (skip80 >> 31) ^ 1u;
-            const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
-            pk[j] = (code & 0x1fu) | (((code >> 8) & 0x1fu) << s1) | (((code >> 16) & 0x1fu) << s2) |
-                    ((code >> 24) << s3);
-            cnt[j] = (int)(k0 + k1 + k2 + k3);
         }
-        const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
-        const uint64_t lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) |
-                            ((uint64_t)pk[3] << sh3);
-        const uint32_t hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
-        const int k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-        const int incl = wave_incl_scan(k, lane);
-        const int total = __shfl(incl, 63);
-        const int64_t bitoff = 5ll * (running + incl - k);
+        uint64_t lo;
+        uint32_t hi;
+        int k, before;   // groups this lane emits, groups emitted by the lanes before it in the record
+        if (__ballot((skip80[0] | skip80[1] | skip80[2] | skip80[3]) != 0u) == 0ull) {
+            // no insert / line break anywhere in this step: byte j is column j, positions are static
+            uint32_t pk[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                pk[j] = (code[j] & 0x1fu) | ((code[j] >> 3) & 0x3e0u) | ((code[j] >> 6) & 0x7c00u) | ((code[j] >> 9) & 0xf8000u);
+            lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << 20) | ((uint64_t)pk[2] << 40) | ((uint64_t)pk[3] << 60);
+            hi = pk[3] >> 4;
+            k = 16;
+            before = 16 * gl;
+        } else {
+            // pack the kept bytes' 5-bit groups densely (a skipped byte contributes no group)
+            uint32_t pk[4];
+            int cnt[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t c = code[j] & ~((skip80[j] >> 7) * 0xffu);
+                const uint32_t k0 = ((skip80[j] >> 7) & 1u) ^ 1u, k1 = ((skip80[j] >> 15) & 1u) ^ 1u;
+                const uint32_t k2 = ((skip80[j] >> 23) & 1u) ^ 1u, k3 = (skip80[j] >> 31) ^ 1u;
+                const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
+                pk[j] = (c & 0x1fu) | (((c >> 8) & 0x1fu) << s1) | (((c >> 16) & 0x1fu) << s2) | ((c >> 24) << s3);
+                cnt[j] = (int)(k0 + k1 + k2 + k3);
+            }
+            const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
+            lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) | ((uint64_t)pk[3] << sh3);
+            hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
+            k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            // inclusive prefix sum inside each record's lane group (DPP: rows of 16, then row carries)
+            int v = k;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+            if (G >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+            if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+            before = v - k;
+        }
+        // every lane of a group needs the group's total: the inclusive sum of its last lane
+        const int incl = before + k;
+        const int total = __shfl(incl, (lane & ~(G - 1)) + G - 1);
+        const int64_t bitoff = 5ll * (running + before);
         const int word0 = (int)(bitoff >> 5);
         const int sh = (int)(bitoff & 31);
         const uint64_t a = lo << sh;
@@ -183,26 +217,28 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             if (v4[i] && word0 + i < W) atomicOr(&row[word0 + i], v4[i]);
         running += total;
     }
-    aligned = wave_sum(aligned);
-    uint32_t *dst = rows + (size_t)seq * W;
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) aligned += __shfl_xor(aligned, d);   // stays inside the group
+    uint32_t *dst = rows + (size_t)(live ? seq : 0) * W;
     int lo4 = 0xffff, hi4 = 0;
-    for (int w = lane * 4, it = 0; it * 256 < W; w += 256, ++it) {
+    for (int w = gl * 4, it = 0; it * 4 * G < W; w += 4 * G, ++it) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         bool differs = false;
-        if (w < W) {
+        if (live && w < W) {
             v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
             *reinterpret_cast<uint4 *>(dst + w) = v;
             differs = ((v.x ^ r0_word(w, L)) | (v.y ^ r0_word(w + 1, L)) | (v.z ^ r0_word(w + 2, L)) |
                        (v.w ^ r0_word(w + 3, L))) != 0u;
         }
-        const unsigned long long d = __ballot(differs);
+        unsigned long long d = __ballot(differs);
+        if (G < 64) d = (d >> (grp * G)) & ((1ull << G) - 1ull);   // this record's lanes only
         if (d) {
-            lo4 = min(lo4, it * 64 + (int)__ffsll((long long)d) - 1);
-            hi4 = max(hi4, it * 64 + 64 - (int)__clzll((long long)d));
+            lo4 = min(lo4, it * G + (int)__ffsll((long long)d) - 1);
+            hi4 = max(hi4, it * G + 64 - (int)__clzll((long long)d));
         }
     }
-    if (lane == 0 && win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
-    if (lane == 0) {
+    if (live && gl == 0) {
+        if (win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
         int st = 0;  // STAG_SEQ_OK
         if (running == 0) st = 5;
         else if (!((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
