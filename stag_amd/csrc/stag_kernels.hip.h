@@ -90,6 +90,25 @@ __device__ __forceinline__ uint32_t r0_word(int w, int L) {
     return v;
 }
 
+// ORs a lane's k 5-bit groups (lo: bits 0..63, hi: bits 64..79) into its record's LDS row at
+// column running + before; returns running + the record's total for this step.
+__device__ __forceinline__ int emit_groups(uint32_t *row, int W, int lane, int G, int running, int before, int k,
+                                           uint64_t lo, uint32_t hi) {
+    // every lane of a group needs the group's total: the inclusive sum of its last lane
+    const int total = __shfl(before + k, (lane & ~(G - 1)) + G - 1);
+    const int64_t bitoff = 5ll * (running + before);
+    const int word0 = (int)(bitoff >> 5);
+    const int sh = (int)(bitoff & 31);
+    const uint64_t a = lo << sh;
+    const uint64_t carry = sh ? lo >> (64 - sh) : 0ull;
+    const uint64_t bb = ((uint64_t)hi << sh) | carry;
+    const uint32_t v4[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bb, (uint32_t)(bb >> 32)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (v4[i] && word0 + i < W) atomicOr(&row[word0 + i], v4[i]);
+    return running + total;
+}
+
 // G = lanes per record (16, 32 or 64): a wave encodes 64/G records side by side, each lane
 // taking 16 bytes of its record per step.  The host picks G so that a record's length wastes few
 // lane slots (a 1,501-byte record is 2 steps of 64 lanes = 2,048 slots, or 3 steps of 32 = 1,536).
@@ -128,19 +147,39 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         const int64_t p = p0 + (int64_t)gl * 16;
         uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
         load16(p + 16 * G, nxt);   // the next vector is in flight while this one is encoded
-        // bytes outside [begin, end) (first and last vector of a record) become '\n' = skipped
-        if (p < begin || p + 16 > end) {
-            const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
-            const int hi_cut = (int)min((int64_t)16, max((int64_t)0, end - p));
+        // valid bytes of this lane's vector: [lo_cut, hi_cut) (first and last vector of a record)
+        const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
+        const int hi_cut = (int)min((int64_t)16, max((int64_t)0, end - p));
+        uint32_t keep[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        if (lo_cut > 0 || hi_cut < 16) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int a0 = min(4, max(0, lo_cut - 4 * j)), b0 = min(4, max(0, hi_cut - 4 * j));
                 const uint32_t below_b = b0 >= 4 ? 0xffffffffu : (1u << (8 * b0)) - 1u;
                 const uint32_t below_a = a0 >= 4 ? 0xffffffffu : (1u << (8 * a0)) - 1u;
-                const uint32_t keep = below_b & ~below_a;
-                wv[j] = (wv[j] & keep) | (0x0a0a0a0au & ~keep);
+                keep[j] = below_b & ~below_a;
             }
         }
+        // Aligned amplicon reads are mostly runs of '-': when every valid byte of every lane is a
+        // gap, the step's output is a prefix of a constant bit pattern (bit 0 of each column).
+        const bool all_gap = ((((wv[0] ^ 0x2d2d2d2du) & keep[0]) | ((wv[1] ^ 0x2d2d2d2du) & keep[1]) |
+                               ((wv[2] ^ 0x2d2d2d2du) & keep[2]) | ((wv[3] ^ 0x2d2d2d2du) & keep[3])) == 0u);
+        if (__ballot(!all_gap) == 0ull) {
+            const int k = max(hi_cut - lo_cut, 0);
+            const uint64_t lo = 5 * k >= 64 ? 0x1084210842108421ull : (0x1084210842108421ull & ((1ull << (5 * k)) - 1ull));
+            const uint32_t hi = 0x842u & ((1u << max(5 * k - 64, 0)) - 1u);
+            int v = k;
+            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+            if (G >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+            if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+            running = emit_groups(row, W, lane, G, running, v - k, k, lo, hi);
+            continue;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wv[j] = (wv[j] & keep[j]) | (0x0a0a0a0au & ~keep[j]);   // invalid -> '\n' = skipped
         // Branch-free SWAR over the 4 dwords: classify 4 bytes at a time.
         uint32_t code[4], skip80[4];
 #pragma unroll
@@ -202,20 +241,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
             before = v - k;
         }
-        // every lane of a group needs the group's total: the inclusive sum of its last lane
-        const int incl = before + k;
-        const int total = __shfl(incl, (lane & ~(G - 1)) + G - 1);
-        const int64_t bitoff = 5ll * (running + before);
-        const int word0 = (int)(bitoff >> 5);
-        const int sh = (int)(bitoff & 31);
-        const uint64_t a = lo << sh;
-        const uint64_t carry = sh ? lo >> (64 - sh) : 0ull;
-        const uint64_t bb = ((uint64_t)hi << sh) | carry;
-        const uint32_t v4[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bb, (uint32_t)(bb >> 32)};
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (v4[i] && word0 + i < W) atomicOr(&row[word0 + i], v4[i]);
-        running += total;
+        running = emit_groups(row, W, lane, G, running, before, k, lo, hi);
     }
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) aligned += __shfl_xor(aligned, d);   // stays inside the group
