@@ -343,7 +343,21 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
         for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) s_cnt[b] = 0;
         __syncthreads();
         int rank = 0;
-        if (nd >= 0) rank = atomicAdd(&s_cnt[nd - lo], 1);
+        if (nbins <= 32) {
+            // a handful of nodes (top levels): 1024 LDS atomics on the same few words would
+            // serialise; count per wave with ballots and add once per (wave, node)
+            int wbase = 0;
+            for (int b = 0; b < nbins; ++b) {
+                const unsigned long long m = __ballot(nd == lo + b);
+                int base_b = 0;
+                if (lane == 0 && m) base_b = atomicAdd(&s_cnt[b], __popcll(m));
+                base_b = __builtin_amdgcn_readfirstlane(base_b);
+                if (nd == lo + b) { wbase = base_b; rank = __popcll(m & ((1ull << lane) - 1ull)); }
+            }
+            rank += wbase;
+        } else if (nd >= 0) {
+            rank = atomicAdd(&s_cnt[nd - lo], 1);
+        }
         __syncthreads();
         for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) {
             const int c = s_cnt[b];
@@ -375,39 +389,39 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
     if (nd >= 0) pos[s] = base + rank;
 }
 
-// One workgroup: exclusive scans over the nodes [lo, hi) of one level.
+// One workgroup: exclusive scans (sequences and tasks) over the nodes [lo, hi) of one level.
+// Each thread owns a contiguous run of nodes; the 1024 run totals are scanned with DPP inside
+// waves and one LDS exchange of the 16 wave totals.
 __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32_t *__restrict__ count,
                                                      int32_t *__restrict__ node_off, int32_t *__restrict__ task_off,
                                                      int32_t *__restrict__ n_tasks) {
-    __shared__ int s_a[1024], s_b[1024];
-    __shared__ int s_carry[2];
-    const int t = threadIdx.x;
-    if (t == 0) { s_carry[0] = 0; s_carry[1] = 0; }
-    __syncthreads();
-    for (int base = lo; base < hi; base += 1024) {
-        const int i = base + t;
-        const int c = i < hi ? count[i] : 0;
-        const int k = (c + TILE - 1) / TILE;
-        s_a[t] = c;
-        s_b[t] = k;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            const int va = t >= d ? s_a[t - d] : 0;
-            const int vb = t >= d ? s_b[t - d] : 0;
-            __syncthreads();
-            s_a[t] += va;
-            s_b[t] += vb;
-            __syncthreads();
-        }
-        if (i < hi) {
-            node_off[i] = s_carry[0] + s_a[t] - c;
-            task_off[i] = s_carry[1] + s_b[t] - k;
-        }
-        __syncthreads();
-        if (t == 1023) { s_carry[0] += s_a[t]; s_carry[1] += s_b[t]; }
-        __syncthreads();
+    __shared__ int s_wa[16], s_wb[16];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = (hi - lo + 1023) / 1024;
+    const int i0 = lo + t * per, i1 = min(hi, i0 + per);
+    int sa = 0, sb = 0;
+    for (int i = i0; i < i1; ++i) {
+        const int c = count[i];
+        sa += c;
+        sb += (c + TILE - 1) / TILE;
     }
-    if (t == 0) *n_tasks = s_carry[1];
+    const int ia = wave_incl_scan(sa, lane), ib = wave_incl_scan(sb, lane);
+    if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
+    __syncthreads();
+    int base_a = 0, base_b = 0, tot_b = 0;
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { base_a += s_wa[w]; base_b += s_wb[w]; }
+        tot_b += s_wb[w];
+    }
+    int ra = base_a + ia - sa, rb = base_b + ib - sb;
+    for (int i = i0; i < i1; ++i) {
+        const int c = count[i];
+        node_off[i] = ra;
+        task_off[i] = rb;
+        ra += c;
+        rb += (c + TILE - 1) / TILE;
+    }
+    if (t == 0) *n_tasks = tot_b;
 }
 
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
