@@ -82,6 +82,34 @@ def test_encode_random_vs_oracle_with_filter_and_newlines():
     del db_L
 
 
+@pytest.mark.parametrize("mean_len,n", [(20, 300), (200, 300), (520, 200), (1100, 150), (4000, 40)])
+def test_encode_every_lane_grouping(mean_len, n):
+    """The encode kernel runs with 16, 32 or 64 lanes per record depending on the average record
+    length; every variant, with gap runs, inserts, ragged lengths and an empty record."""
+    rng = np.random.default_rng(mean_len)
+    strings = []
+    for i in range(n):
+        m = max(1, int(rng.normal(mean_len, mean_len * 0.1)))
+        s = np.full(m, "-", dtype="<U1")
+        a, b = sorted(rng.integers(0, m + 1, size=2))
+        s[a:b] = rng.choice(list("ACGTUN"), size=b - a)
+        s = list(s)
+        for _ in range(int(rng.integers(0, 4))):
+            s.insert(int(rng.integers(0, len(s) + 1)), str(rng.choice(list("acgt"))))
+        strings.append("".join(s))
+    strings[n // 2] = ""
+    L = 5 * max(len(x) for x in strings)
+    bits, n_char, n_al, status = encode_raw(strings, L)
+    dense = tables.unpack_rows(bits, bits.shape[1] * 32)
+    for i, s in enumerate(strings):
+        exp, e_char, e_al = oracle_c.encode_a2m(s)
+        assert n_char[i] == e_char and n_al[i] == e_al, (i, len(s))
+        assert np.array_equal(dense[i, :5 * e_char], exp), (i, len(s))
+        assert not dense[i, 5 * e_char:].any()
+        assert status[i] == (_lib.SEQ_ZERO_COLUMNS if e_char == 0 else
+                             _lib.SEQ_OK if 5 * e_char == L else _lib.SEQ_LENGTH_MISMATCH)
+
+
 @pytest.mark.parametrize("case", gu.load("classify_seq.json"), ids=lambda c: c["name"])
 def test_classify_seq_golden(case):
     taxonomy, tax_function, classifiers = gu.db_from_json(case)
