@@ -79,8 +79,9 @@ struct stag_db {
     DevBuf<double> tf;
     // workspace (grown by reserve)
     int64_t cap_n = 0;
-    DevBuf<int32_t> node, pos, count, node_off, task_off, n_tasks;
+    DevBuf<int32_t> node, pos, count, task_off, n_tasks;
     DevBuf<SeqRef> order;
+    DevBuf<LevelRec> lvl;
     DevBuf<Task> tasks;
     DevBuf<uint32_t> bits, win;
     DevBuf<double> chunkgap;
@@ -97,7 +98,7 @@ struct stag_db {
     void free_all() {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
-        count.release(); node_off.release(); task_off.release(); n_tasks.release(); tasks.release();
+        count.release(); lvl.release(); task_off.release(); n_tasks.release(); tasks.release();
         bits.release(); win.release(); chunkgap.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
         r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
@@ -207,11 +208,12 @@ int reserve_walk(stag_db *db, int64_t n) {
     int rc;
     if ((rc = db->node.reserve(n))) return rc;
     if ((rc = db->pos.reserve(n))) return rc;
-    if ((rc = db->order.reserve(n))) return rc;
+    const size_t max_tasks = (size_t)n / TILE + db->max_level_nodes + 2;
+    if ((rc = db->order.reserve(max_tasks * TILE))) return rc;   // 64 slots per task
+    if ((rc = db->lvl.reserve((size_t)std::max(db->max_depth, 1) * n))) return rc;
     if ((rc = db->win.reserve(n))) return rc;
-    if ((rc = db->tasks.reserve(n / TILE + db->max_level_nodes + 2))) return rc;
+    if ((rc = db->tasks.reserve(max_tasks))) return rc;
     if ((rc = db->count.reserve(db->n_nodes))) return rc;
-    if ((rc = db->node_off.reserve(db->n_nodes))) return rc;
     if ((rc = db->task_off.reserve(db->n_nodes))) return rc;
     if ((rc = db->n_tasks.reserve(std::max(db->max_depth, 1)))) return rc;
     if ((rc = reserve_results(db, n))) return rc;
@@ -249,29 +251,31 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     {
         Prof p(db, st, 2);
         HIP_TRY(hipMemsetAsync(db->count.p, 0, sizeof(int32_t) * db->n_nodes, st));
-        hipLaunchKernelGGL(k_init_walk, dim3(g256), dim3(256), 0, st, n, D, d_status_in, o.status, db->node.p,
-                           o.path_node, o.path_len);
+        if (db->max_depth == 0)
+            hipLaunchKernelGGL(k_init_status, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status);
     }
     int rc;
-    if ((rc = launch_check("k_init_walk"))) return rc;
+    if ((rc = launch_check("k_init_status"))) return rc;
     for (int d = 0; d < db->max_depth; ++d) {
         const int lo = db->level_start[d], hi = db->level_start[d + 1];
+        LevelRec *cur = db->lvl.p + (size_t)d * n;
         {
             Prof p(db, st, 2);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_THREADS - 1) / ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, st,
-                               n, lo, hi, db->node.p, db->count.p, db->pos.p);
-            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->node_off.p,
-                               db->task_off.p, db->n_tasks.p + d);
+                               n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, db->node.p,
+                               db->count.p, db->pos.p);
+            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->task_off.p,
+                               db->n_tasks.p + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, db->node.p, db->pos.p, db->count.p,
-                               db->node_off.p, db->task_off.p, db->child_first.p, db->node_err.p, db->win.p, db->order.p, db->tasks.p);
+                               db->task_off.p, db->child_first.p, db->node_err.p, db->win.p, db->order.p, db->tasks.p);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
-        a.bits = d_bits; a.W = db->W; a.NC = db->nchunks; a.depth = d; a.D = D;
+        a.bits = d_bits; a.W = db->W; a.NC = db->nchunks;
         a.n_tasks = db->n_tasks.p + d; a.tasks = db->tasks.p; a.order = db->order.p;
-        a.child_first = db->child_first.p; a.intercept = db->intercept.p;
-        a.blk_off = db->blk_off.p; a.blocks = db->blocks.p; a.node = db->node.p;
-        a.path_node = o.path_node; a.path_prob = o.path_prob; a.path_len = o.path_len; a.status = o.status;
+        a.intercept = db->intercept.p;
+        a.blk_off = db->blk_off.p; a.blocks = db->blocks.p;
+        a.lvl = cur; a.status = o.status;
         a.chunkgap = db->chunkgap.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
@@ -282,12 +286,12 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     }
     {
         Prof p(db, st, 3);
-        const size_t lds = (size_t)256 * (D + db->n_keys) * sizeof(double);
+        const size_t lds = (size_t)256 * ((D + db->n_keys) * sizeof(double) + D * sizeof(int32_t));
         if (lds > 160 * 1024) return fail(STAG_E_INVALID, "tree depth %d + %d rank-cut keys exceed the rank-cut kernel's LDS tile", D, db->n_keys);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_rankcut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), lds, st, n, D, db->n_keys, db->n_tf, db->tf.p, o.path_len,
-                           o.path_prob, o.lead, o.level_prob, o.selected, o.status);
+        hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), lds, st, n, D, db->max_depth, db->n_keys, db->n_tf, db->tf.p,
+                           db->lvl.p, o.path_node, o.path_prob, o.path_len, o.lead, o.level_prob, o.selected, o.status);
     }
     return launch_check("k_rankcut");
 }

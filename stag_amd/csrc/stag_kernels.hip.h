@@ -43,12 +43,22 @@ __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
 }
 
 struct Task {       // 32 bytes: one s_load_dwordx8 tells a workgroup everything about its task
-    int32_t node, start, count, err;   // err: status every sequence reaching this node gets (0 = fine)
-    int32_t c0, k, pad0, pad1;         // children of node: ids c0 .. c0+k-1
+    int32_t node, pad2, count, err;    // err: status every sequence reaching this node gets (0 = fine)
+    int32_t c0, k, pad0, pad1;         // children of node: ids c0 .. c0+k-1 (k == 0: a leaf, the walk ends)
 };
-struct SeqRef {     // order[]: a sequence id and its R0 window, so the walk needs one load, not two
+// order[]: a sequence id and its R0 window, so the walk needs one load, not two.  Task t owns the
+// 64 slots order[64 t .. 64 t + 63] (the first `count` are filled): the walk can fetch its task
+// record and its sequences at the same time instead of one after the other.
+struct SeqRef {
     int32_t seq;
     uint32_t win;
+};
+// What one level of the walk decides for one sequence; lvl[depth][seq], one 16-byte store.
+// node < 0: the walk of this sequence has ended before this level.
+struct __attribute__((aligned(16))) LevelRec {
+    int32_t node;
+    int32_t pad;
+    double prob;        // 2.0 = "single child" placeholder (classify.py:37)
 };
 // plain vector types: unlike HIP's uint4 class they can be loaded from the constant address space
 using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
@@ -309,16 +319,12 @@ __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restric
 // ------------------------------------------------------------------------------------------
 // grouping by current node
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_walk(int64_t n, int D, const int32_t *__restrict__ status_in,
-                                                   int32_t *__restrict__ status, int32_t *__restrict__ node,
-                                                   int32_t *__restrict__ path_node, int32_t *__restrict__ path_len) {
+// Only for a tree without levels (a root with no children): status is otherwise set by the
+// first k_assign.
+__global__ __launch_bounds__(256) void k_init_status(int64_t n, const int32_t *__restrict__ status_in,
+                                                     int32_t *__restrict__ status) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s >= n) return;
-    const int st = status_in ? status_in[s] : 0;
-    status[s] = st;
-    node[s] = st == 0 ? 0 : -1;
-    path_len[s] = 0;
-    for (int d = 0; d < D; ++d) path_node[s * D + d] = -1;
+    if (s < n) status[s] = status_in ? status_in[s] : 0;
 }
 
 // pos[s] = rank of s among the sequences of its node, count[node] = sequences at that node.
@@ -330,14 +336,36 @@ __global__ __launch_bounds__(256) void k_init_walk(int64_t n, int D, const int32
 constexpr int ASSIGN_BINS = 15360;   // 60 KB of LDS counters
 constexpr int ASSIGN_THREADS = 1024;
 
+//
+// The node a sequence stands on comes from the previous level's record (level 0: the root for
+// every sequence whose incoming status is OK; that status is copied to the output here).  A
+// sequence that is not on a node of this level has ended its walk: its record of this level
+// says so, which is what the next level and the rank cut read.
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, int hi,
-                                                           const int32_t *__restrict__ node,
+                                                           const LevelRec *__restrict__ prev,
+                                                           LevelRec *__restrict__ cur,
+                                                           const int32_t *__restrict__ status_in,
+                                                           int32_t *__restrict__ status,
+                                                           int32_t *__restrict__ node,
                                                            int32_t *__restrict__ count, int32_t *__restrict__ pos) {
     __shared__ int s_cnt[ASSIGN_BINS];
     const int64_t s = (int64_t)blockIdx.x * ASSIGN_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int nd = s < n ? node[s] : -1;
-    if (nd < lo || nd >= hi) nd = -1;
+    int nd = -1;
+    if (s < n) {
+        if (prev) {
+            nd = prev[s].node;
+        } else {
+            const int st = status_in ? status_in[s] : 0;
+            status[s] = st;
+            nd = st == 0 ? 0 : -1;
+        }
+        if (nd < lo || nd >= hi) {
+            nd = -1;
+            cur[s].node = -1;
+        }
+        node[s] = nd;
+    }
     const int nbins = hi - lo;
     if (nbins <= ASSIGN_BINS) {
         for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) s_cnt[b] = 0;
@@ -389,44 +417,36 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
     if (nd >= 0) pos[s] = base + rank;
 }
 
-// One workgroup: exclusive scans (sequences and tasks) over the nodes [lo, hi) of one level.
+// One workgroup: exclusive scan of the task counts over the nodes [lo, hi) of one level.
 // Each thread owns a contiguous run of nodes; the 1024 run totals are scanned with DPP inside
 // waves and one LDS exchange of the 16 wave totals.
 __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32_t *__restrict__ count,
-                                                     int32_t *__restrict__ node_off, int32_t *__restrict__ task_off,
+                                                     int32_t *__restrict__ task_off,
                                                      int32_t *__restrict__ n_tasks) {
-    __shared__ int s_wa[16], s_wb[16];
+    __shared__ int s_wb[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (hi - lo + 1023) / 1024;
     const int i0 = lo + t * per, i1 = min(hi, i0 + per);
-    int sa = 0, sb = 0;
-    for (int i = i0; i < i1; ++i) {
-        const int c = count[i];
-        sa += c;
-        sb += (c + TILE - 1) / TILE;
-    }
-    const int ia = wave_incl_scan(sa, lane), ib = wave_incl_scan(sb, lane);
-    if (lane == 63) { s_wa[wave] = ia; s_wb[wave] = ib; }
+    int sb = 0;
+    for (int i = i0; i < i1; ++i) sb += (count[i] + TILE - 1) / TILE;
+    const int ib = wave_incl_scan(sb, lane);
+    if (lane == 63) s_wb[wave] = ib;
     __syncthreads();
-    int base_a = 0, base_b = 0, tot_b = 0;
+    int base_b = 0, tot_b = 0;
     for (int w = 0; w < 16; ++w) {
-        if (w < wave) { base_a += s_wa[w]; base_b += s_wb[w]; }
+        if (w < wave) base_b += s_wb[w];
         tot_b += s_wb[w];
     }
-    int ra = base_a + ia - sa, rb = base_b + ib - sb;
+    int rb = base_b + ib - sb;
     for (int i = i0; i < i1; ++i) {
-        const int c = count[i];
-        node_off[i] = ra;
         task_off[i] = rb;
-        ra += c;
-        rb += (c + TILE - 1) / TILE;
+        rb += (count[i] + TILE - 1) / TILE;
     }
     if (t == 0) *n_tasks = tot_b;
 }
 
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ count,
-                                                 const int32_t *__restrict__ node_off,
                                                  const int32_t *__restrict__ task_off,
                                                  const int32_t *__restrict__ child_first,
                                                  const uint8_t *__restrict__ node_err, const uint32_t *__restrict__ win,
@@ -436,16 +456,16 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
     const int nd = node[s];
     if (nd < lo || nd >= hi) return;
     const int p = pos[s];
-    const int at = node_off[nd] + p;
+    const int task = task_off[nd] + p / TILE;
     SeqRef ref;
     ref.seq = (int32_t)s;
     ref.win = win[s];
-    order[at] = ref;
+    order[(size_t)task * TILE + (p & (TILE - 1))] = ref;
     if ((p & (TILE - 1)) == 0) {
         Task tk;
-        tk.node = nd; tk.start = at; tk.count = min(TILE, count[nd] - p); tk.err = node_err[nd];
+        tk.node = nd; tk.pad2 = 0; tk.count = min(TILE, count[nd] - p); tk.err = node_err[nd];
         tk.c0 = child_first[nd]; tk.k = child_first[nd + 1] - tk.c0; tk.pad0 = 0; tk.pad1 = 0;
-        tasks[task_off[nd] + p / TILE] = tk;
+        tasks[task] = tk;
     }
 }
 
@@ -468,19 +488,15 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
 // ------------------------------------------------------------------------------------------
 struct WalkArgs {
     const uint32_t *bits;       // [n][W]
-    int W, NC, depth, D;        // NC = chunks per row
+    int W, NC;                  // NC = chunks per row
     const int32_t *n_tasks;
     const Task *tasks;
     const SeqRef *order;
-    const int32_t *child_first;
     const double *intercept;
     const uint32_t *blk_off;    // [n_nodes*NC + 1]
     const double *chunkgap;     // [n_nodes][NC] (+8 padding): sum of a chunk's coefficients on "others" bits
     const uint4 *blocks;        // Entry[4] per block
-    int32_t *node;              // [n] in: current node; out: next node or -1
-    int32_t *path_node;         // [n][D]
-    double *path_prob;          // [n][D]  (2.0 = "single child" placeholder, classify.py:37)
-    int32_t *path_len;
+    LevelRec *lvl;              // [n] this level's records
     int32_t *status;
 };
 
@@ -548,34 +564,41 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     __shared__ uint4 s_buf[NW][ENT_PIECE];
     static_assert(ENT_PIECE * 16 >= TILE * 12, "result slot must fit the coefficient buffer");
 
+    const int lane = threadIdx.x & 63;
     const int n_tasks = *as_const(a.n_tasks);
     const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[blockIdx.x];
+    // the task's slots of order[] sit at a fixed place: fetched together with the task record
+    // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
+    SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];
     if ((int)blockIdx.x >= n_tasks) return;
-    const int32_t STAG_CONST *child_first = as_const(a.child_first);
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
-    const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node = tk[0], err = tk[3], c0 = tk[4], k = tk[5];
-    (void)node;
-    SeqRef me;
-    me.seq = -1;
-    me.win = 0xffffu;
-    if (lane < tk[2]) me = a.order[tk[1] + lane];
+    const int err = tk[3], c0 = tk[4], k = tk[5];
+    if (lane >= tk[2]) {
+        me.seq = -1;
+        me.win = 0xffffu;
+    }
     const int seq = me.seq;
+    auto put = [&](int node_out, double prob) {
+        LevelRec r;
+        r.node = node_out;
+        r.pad = 0;
+        r.prob = prob;
+        a.lvl[seq] = r;
+    };
     uint4 *s_ent = s_buf[wave];
     auto s_z = [&](int w) { return reinterpret_cast<double *>(s_buf[w]); };
     auto s_c = [&](int w) { return reinterpret_cast<int *>(s_buf[w]) + 2 * TILE; };
 
-    if (k == 1 || err) {  // nothing to score (classify.py:35-37) or the reference raises
+    if (k <= 1 || err) {  // a leaf; nothing to score (classify.py:35-37); or the reference raises
         if (wave == 0 && seq >= 0) {
-            if (k == 1) {
-                a.path_node[(size_t)seq * a.D + a.depth] = c0;
-                a.path_prob[(size_t)seq * a.D + a.depth] = 2.0;
-                a.path_len[seq] = a.depth + 1;
-                a.node[seq] = child_first[c0 + 1] > child_first[c0] ? c0 : -1;
-            } else {
+            if (err) {
                 a.status[seq] = err;
-                a.node[seq] = -1;
+                put(-1, 0.0);
+            } else if (k == 1) {
+                put(c0, 2.0);
+            } else {
+                put(-1, 0.0);
             }
         }
         return;
@@ -689,40 +712,44 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             const int cc = s_c(w)[lane];
             if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
         }
-        if (best_c >= 0) {
-            a.path_node[(size_t)seq * a.D + a.depth] = best_c;
-            a.path_prob[(size_t)seq * a.D + a.depth] = best_p;
-            a.path_len[seq] = a.depth + 1;
-            a.node[seq] = a.child_first[best_c + 1] > a.child_first[best_c] ? best_c : -1;
-        } else {
-            a.node[seq] = -1;  // every probability was NaN: the reference stops here (classify.py:49)
-        }
+        // best_c < 0: every probability was NaN, the reference stops here (classify.py:49)
+        put(best_c, best_c >= 0 ? best_p : 0.0);
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // rank cut: classify.py:106-110 (placeholder fix-up) and :58-72 (find_correct_level)
 // ------------------------------------------------------------------------------------------
-// One workgroup = 256 sequences.  Their path probabilities ([256][D] doubles, contiguous in
-// HBM) are moved through LDS with coalesced loads/stores; each thread then works on its own
-// D values in LDS (a thread touching its own 56-byte slice of HBM costs one cache line per lane).
-__global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int K, int n_tf, const double *__restrict__ tf,
-                                                 const int32_t *__restrict__ path_len, double *__restrict__ path_prob,
-                                                 int32_t *__restrict__ n_lead_single, double *__restrict__ level_prob,
-                                                 int32_t *__restrict__ selected, int32_t *__restrict__ status) {
-    extern __shared__ double s_rc[];   // [256][D] path probabilities, then [256][K] level probabilities
+// One workgroup = 256 sequences, one thread per sequence.  A thread gathers its records of all
+// levels (lvl[d][s]: coalesced across the workgroup), works on its own slice of LDS, and the
+// [256][D] / [256][K] tiles then leave through coalesced stores (a thread storing its own 56-byte
+// slice of HBM would cost one cache line per lane).
+__global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int levels, int K, int n_tf,
+                                                 const double *__restrict__ tf, const LevelRec *__restrict__ lvl,
+                                                 int32_t *__restrict__ path_node, double *__restrict__ path_prob,
+                                                 int32_t *__restrict__ path_len, int32_t *__restrict__ n_lead_single,
+                                                 double *__restrict__ level_prob, int32_t *__restrict__ selected,
+                                                 int32_t *__restrict__ status) {
+    extern __shared__ double s_rc[];   // [256][D] path probabilities, [256][K] level probabilities, [256][D] node ids
     const int64_t s0 = (int64_t)blockIdx.x * 256;
     const int cnt = (int)min((int64_t)256, n - s0);
     double *s_pp = s_rc, *s_lp = s_rc + 256 * D;
-    for (int i = threadIdx.x; i < cnt * D; i += 256) s_pp[i] = path_prob[(size_t)s0 * D + i];
-    __syncthreads();
+    int32_t *s_pn = reinterpret_cast<int32_t *>(s_lp + 256 * K);
     const int64_t s = s0 + threadIdx.x;
     if (threadIdx.x < cnt) {
         int sel = -1, lead = 0;
         int st = status[s];
-        const int len = path_len[s];
         double *pp = s_pp + threadIdx.x * D;
         double *lp = s_lp + threadIdx.x * K;
+        int32_t *pn = s_pn + threadIdx.x * D;
+        int len = levels;
+        for (int d = 0; d < levels; ++d) {   // independent loads; the walk ended at the first node < 0
+            const LevelRec r = lvl[(size_t)d * n + s];
+            pp[d] = r.prob;
+            pn[d] = r.node;
+            if (r.node < 0) len = min(len, d);
+        }
+        for (int d = len; d < D; ++d) pn[d] = -1;
         const double STAG_CONST *tfc = as_const(tf);
         for (int kk = 0; kk < K; ++kk) lp[kk] = 0.0;
         if (st == 0 && len == 0) st = 4;  // perc[0] on an empty list
@@ -761,12 +788,16 @@ __global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int K, int n_
         } else {
             for (int i = 0; i < D; ++i) pp[i] = 0.0;
         }
+        path_len[s] = len;
         n_lead_single[s] = lead;
         selected[s] = sel;
         status[s] = st;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < cnt * D; i += 256) path_prob[(size_t)s0 * D + i] = s_pp[i];
+    for (int i = threadIdx.x; i < cnt * D; i += 256) {
+        path_prob[(size_t)s0 * D + i] = s_pp[i];
+        path_node[(size_t)s0 * D + i] = s_pn[i];
+    }
     for (int i = threadIdx.x; i < cnt * K; i += 256) level_prob[(size_t)s0 * K + i] = s_lp[i];
 }
 
