@@ -261,7 +261,7 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
         LevelRec *cur = db->lvl.p + (size_t)d * n;
         {
             Prof p(db, st, 2);
-            hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_THREADS - 1) / ASSIGN_THREADS)), dim3(ASSIGN_THREADS), 0, st,
+            hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
                                n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, db->node.p,
                                db->count.p, db->pos.p);
             hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->task_off.p,

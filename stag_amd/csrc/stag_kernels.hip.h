@@ -335,6 +335,9 @@ __global__ __launch_bounds__(256) void k_init_status(int64_t n, const int32_t *_
 //  * wider levels: per-wave grouping by ballot (ALU only), then one atomic per (wave, node).
 constexpr int ASSIGN_BINS = 15360;   // 60 KB of LDS counters
 constexpr int ASSIGN_THREADS = 1024;
+constexpr int ASSIGN_ITEMS = 4;      // sequences per thread: a workgroup counts 4,096 sequences, so a
+                                     // hot node takes a quarter of the same-address global atomics
+constexpr int ASSIGN_SPAN = ASSIGN_THREADS * ASSIGN_ITEMS;
 
 //
 // The node a sequence stands on comes from the previous level's record (level 0: the root for
@@ -349,72 +352,107 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
                                                            int32_t *__restrict__ node,
                                                            int32_t *__restrict__ count, int32_t *__restrict__ pos) {
     __shared__ int s_cnt[ASSIGN_BINS];
-    const int64_t s = (int64_t)blockIdx.x * ASSIGN_THREADS + threadIdx.x;
     const int lane = threadIdx.x & 63;
-    int nd = -1;
-    if (s < n) {
-        if (prev) {
-            nd = prev[s].node;
-        } else {
-            const int st = status_in ? status_in[s] : 0;
-            status[s] = st;
-            nd = st == 0 ? 0 : -1;
+    const int64_t s0 = (int64_t)blockIdx.x * ASSIGN_SPAN + threadIdx.x;
+    int nd[ASSIGN_ITEMS];
+#pragma unroll
+    for (int j = 0; j < ASSIGN_ITEMS; ++j) {
+        const int64_t s = s0 + (int64_t)j * ASSIGN_THREADS;
+        nd[j] = -1;
+        if (s < n) {
+            if (prev) {
+                nd[j] = prev[s].node;
+            } else {
+                const int st = status_in ? status_in[s] : 0;
+                status[s] = st;
+                nd[j] = st == 0 ? 0 : -1;
+            }
+            if (nd[j] < lo || nd[j] >= hi) {
+                nd[j] = -1;
+                cur[s].node = -1;
+            }
+            node[s] = nd[j];
         }
-        if (nd < lo || nd >= hi) {
-            nd = -1;
-            cur[s].node = -1;
-        }
-        node[s] = nd;
     }
     const int nbins = hi - lo;
+    int rank[ASSIGN_ITEMS];
     if (nbins <= ASSIGN_BINS) {
         for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) s_cnt[b] = 0;
         __syncthreads();
-        int rank = 0;
         if (nbins <= 32) {
-            // a handful of nodes (top levels): 1024 LDS atomics on the same few words would
+            // a handful of nodes (top levels): thousands of LDS atomics on the same few words would
             // serialise; count per wave with ballots and add once per (wave, node)
-            int wbase = 0;
+#pragma unroll
+            for (int j = 0; j < ASSIGN_ITEMS; ++j) rank[j] = 0;
             for (int b = 0; b < nbins; ++b) {
-                const unsigned long long m = __ballot(nd == lo + b);
+                unsigned long long m[ASSIGN_ITEMS];
+                int tot = 0;
+#pragma unroll
+                for (int j = 0; j < ASSIGN_ITEMS; ++j) {
+                    m[j] = __ballot(nd[j] == lo + b);
+                    tot += __popcll(m[j]);
+                }
                 int base_b = 0;
-                if (lane == 0 && m) base_b = atomicAdd(&s_cnt[b], __popcll(m));
+                if (lane == 0 && tot) base_b = atomicAdd(&s_cnt[b], tot);
                 base_b = __builtin_amdgcn_readfirstlane(base_b);
-                if (nd == lo + b) { wbase = base_b; rank = __popcll(m & ((1ull << lane) - 1ull)); }
+#pragma unroll
+                for (int j = 0; j < ASSIGN_ITEMS; ++j) {
+                    if (nd[j] == lo + b) rank[j] = base_b + __popcll(m[j] & ((1ull << lane) - 1ull));
+                    base_b += __popcll(m[j]);
+                }
             }
-            rank += wbase;
-        } else if (nd >= 0) {
-            rank = atomicAdd(&s_cnt[nd - lo], 1);
+        } else {
+#pragma unroll
+            for (int j = 0; j < ASSIGN_ITEMS; ++j) rank[j] = nd[j] >= 0 ? atomicAdd(&s_cnt[nd[j] - lo], 1) : 0;
         }
         __syncthreads();
-        for (int b = threadIdx.x; b < nbins; b += ASSIGN_THREADS) {
-            const int c = s_cnt[b];
-            s_cnt[b] = c ? atomicAdd(&count[lo + b], c) : 0;
+        // one global atomic per non-empty bin; four bins per thread and step so that the returning
+        // atomics are in flight together instead of one round trip after the other
+        for (int b0 = threadIdx.x; b0 < nbins; b0 += 4 * ASSIGN_THREADS) {
+            int c[4], r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * ASSIGN_THREADS;
+                c[u] = b < nbins ? s_cnt[b] : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&count[lo + b0 + u * ASSIGN_THREADS], c[u]) : 0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u * ASSIGN_THREADS;
+                if (b < nbins) s_cnt[b] = r[u];
+            }
         }
         __syncthreads();
-        if (nd >= 0) pos[s] = s_cnt[nd - lo] + rank;
+#pragma unroll
+        for (int j = 0; j < ASSIGN_ITEMS; ++j)
+            if (nd[j] >= 0) pos[s0 + (int64_t)j * ASSIGN_THREADS] = s_cnt[nd[j] - lo] + rank[j];
         return;
     }
-    bool todo = nd >= 0;
-    int rank = 0, cnt = 0, leader_lane = lane;
-    for (;;) {
-        const unsigned long long pending = __ballot(todo);
-        if (!pending) break;
-        const int leader = __ffsll((long long)pending) - 1;
-        const int n0 = __shfl(nd, leader);
-        const bool mine = todo && nd == n0;
-        const unsigned long long same = __ballot(mine);
-        if (mine) {
-            rank = __popcll(same & ((1ull << lane) - 1ull));
-            cnt = __popcll(same);
-            leader_lane = leader;
-            todo = false;
+#pragma unroll
+    for (int j = 0; j < ASSIGN_ITEMS; ++j) {
+        const int ndj = nd[j];
+        bool todo = ndj >= 0;
+        int rk = 0, cnt = 0, leader_lane = lane;
+        for (;;) {
+            const unsigned long long pending = __ballot(todo);
+            if (!pending) break;
+            const int leader = __ffsll((long long)pending) - 1;
+            const int n0 = __shfl(ndj, leader);
+            const bool mine = todo && ndj == n0;
+            const unsigned long long same = __ballot(mine);
+            if (mine) {
+                rk = __popcll(same & ((1ull << lane) - 1ull));
+                cnt = __popcll(same);
+                leader_lane = leader;
+                todo = false;
+            }
         }
+        int base = 0;
+        if (ndj >= 0 && lane == leader_lane) base = atomicAdd(&count[ndj], cnt);
+        base = __shfl(base, leader_lane);
+        if (ndj >= 0) pos[s0 + (int64_t)j * ASSIGN_THREADS] = base + rk;
     }
-    int base = 0;
-    if (nd >= 0 && lane == leader_lane) base = atomicAdd(&count[nd], cnt);
-    base = __shfl(base, leader_lane);
-    if (nd >= 0) pos[s] = base + rank;
 }
 
 // One workgroup: exclusive scan of the task counts over the nodes [lo, hi) of one level.
@@ -642,9 +680,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
             const int sB = min(wB, sA + WCAP_CHUNKS);
             // this wave's coefficient range of the slice: contiguous, chunk after chunk
-            uint32_t e_lo = 0, e_hi = 0;
-            if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
-            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
+            uint32_t eb[WCAP_CHUNKS + 1];   // first entry of each chunk of the slice (clamped at its end)
+#pragma unroll
+            for (int i = 0; i <= WCAP_CHUNKS; ++i) eb[i] = active ? bo[min(sA + i, sB)] * BLOCK_ENTRIES : 0u;
+            const uint32_t e_hi = eb[WCAP_CHUNKS];
+            uint32_t piece = eb[0];   // first entry held in s_ent[wave]
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             if (lane < ENT_PIECE && piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
             if (!one_slice || pass0 == 0) {
@@ -668,10 +708,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
                                      (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-                for (int ch = sA + ((part - sA) & (P - 1)); ch < sB; ch += P) {
-                    const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
+#pragma unroll
+                for (int i = 0; i < WCAP_CHUNKS; ++i) {
+                    if (sA + i >= sB || (((sA + i) & (P - 1)) != part)) continue;   // wave-uniform
                     double cs = 0.0;
-                    for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                    for (uint32_t e = eb[i]; e < eb[i + 1]; e += BLOCK_ENTRIES) {
                         if (e >= piece + ENT_PIECE) {   // rare: more than 48 coefficients in the slice
                             piece = e;
                             if (lane < ENT_PIECE)
