@@ -680,11 +680,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
             const int sB = min(wB, sA + WCAP_CHUNKS);
             // this wave's coefficient range of the slice: contiguous, chunk after chunk
-            uint32_t eb[WCAP_CHUNKS + 1];   // first entry of each chunk of the slice (clamped at its end)
-#pragma unroll
-            for (int i = 0; i <= WCAP_CHUNKS; ++i) eb[i] = active ? bo[min(sA + i, sB)] * BLOCK_ENTRIES : 0u;
-            const uint32_t e_hi = eb[WCAP_CHUNKS];
-            uint32_t piece = eb[0];   // first entry held in s_ent[wave]
+            uint32_t e_lo = 0, e_hi = 0;
+            if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
+            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
             if (lane < ENT_PIECE && piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
             if (!one_slice || pass0 == 0) {
@@ -708,11 +706,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
                                      (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-#pragma unroll
-                for (int i = 0; i < WCAP_CHUNKS; ++i) {
-                    if (sA + i >= sB || (((sA + i) & (P - 1)) != part)) continue;   // wave-uniform
+                for (int ch = sA + ((part - sA) & (P - 1)); ch < sB; ch += P) {
+                    const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
                     double cs = 0.0;
-                    for (uint32_t e = eb[i]; e < eb[i + 1]; e += BLOCK_ENTRIES) {
+                    for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
                         if (e >= piece + ENT_PIECE) {   // rare: more than 48 coefficients in the slice
                             piece = e;
                             if (lane < ENT_PIECE)
