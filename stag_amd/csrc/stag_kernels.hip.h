@@ -547,9 +547,9 @@ __device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 
     return __hiloint2double((int)e.w & m, (int)e.z & m);
 }
 
-// z += chunkgap[ch] for the chunks lo <= ch < hi of this wave's class (ch % P == part), in
-// increasing order.  Values arrive 8 at a time through one scalar load (the array is padded).
-__device__ __forceinline__ double add_outside(double z, const double STAG_CONST *cg, int lo, int hi, int part, int P) {
+// z += chunkgap[ch] for lo <= ch < hi, in increasing order.  Values arrive 8 at a time through
+// one scalar load (the array is padded).
+__device__ __forceinline__ double add_outside(double z, const double STAG_CONST *cg, int lo, int hi) {
     for (int g = lo & ~7; g < hi; g += 8) {
         double d[8];
 #pragma unroll
@@ -557,7 +557,7 @@ __device__ __forceinline__ double add_outside(double z, const double STAG_CONST 
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ch = g + j;
-            if (ch >= lo && ch < hi && ((ch & (P - 1)) == part)) z += d[j];
+            if (ch >= lo && ch < hi) z += d[j];
         }
     }
     return z;
@@ -653,30 +653,28 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     const int cB = min(wave_max_i(hi), a.NC);
     const bool one_slice = cB - cA <= WCAP_CHUNKS;   // the usual case: staged once for all siblings
 
-    // Siblings are scored NW at a time ("pass"), one per wave; a pass with fewer than NW
-    // siblings gives each sibling P = NW / siblings waves (a power of two), wave `part` taking the
-    // chunks ch with ch % P == part.
+    // Siblings are scored NW at a time ("pass"), one per wave.  (Splitting a sibling's chunks over
+    // the idle waves of a short pass was measured slower: the kernel is bound by instruction
+    // issue, not by the length of one wave's chain.)
     //
-    // CANONICAL SUMMATION.  A wave adds, in increasing chunk order, one term per chunk of its
-    // class: inside the window the lane's own sum over that chunk's coefficients (in stored
+    // CANONICAL SUMMATION.  z is one chain over the chunks in increasing order, one term per
+    // chunk: inside the window the lane's own sum over that chunk's coefficients (in stored
     // order, one accumulator), outside it chunkgap[ch], which the host computed with the same
     // additions for a row that equals R0 there.  So a score depends only on (row, node): not on
-    // which other rows share the task, nor on how wide the task's window is.  That keeps
-    // results bit-identical from run to run (task composition comes from atomics) and makes
-    // identical sibling rows tie exactly, so the first stored child wins as in classify.py:41.
+    // which other rows share the task, nor on how wide the task's window is.  That keeps results
+    // bit-identical from run to run (task composition comes from atomics) and makes identical
+    // sibling rows tie exactly, so the first stored child wins as in classify.py:41.  (A table of
+    // the chain's prefix sums, one load instead of the loop before the window, measured 20 % slower.)
     double best_p = -1.0;
     int best_c = -1;
     const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
     for (int pass0 = 0; pass0 < k; pass0 += NW) {
-        const int kk = min(NW, k - pass0);
-        const int P = NW / kk;
-        const int ci = wave / P, part = wave - ci * P;
-        const bool active = ci < kk;
-        const int c = c0 + pass0 + ci;
+        const bool active = pass0 + wave < k;
+        const int c = c0 + pass0 + wave;
         const double STAG_CONST *cg = as_const(a.chunkgap) + (size_t)c * a.NC;
         const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
         double z = 0.0;
-        if (active) z = add_outside(z, cg, 0, wA, part, P);
+        if (active) z = add_outside(z, cg, 0, wA);
         for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
             const int sB = min(wB, sA + WCAP_CHUNKS);
             // this wave's coefficient range of the slice: contiguous, chunk after chunk
@@ -706,7 +704,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
                                      (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-                for (int ch = sA + ((part - sA) & (P - 1)); ch < sB; ch += P) {
+                for (int ch = sA; ch < sB; ++ch) {
                     const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
                     double cs = 0.0;
                     for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
@@ -726,17 +724,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 }
             }
         }
-        if (active) z = add_outside(z, cg, wB, a.NC, part, P);
-        if (P > 1) {  // workgroup-uniform: combine the P class sums of each sibling in a fixed order
-            s_z(wave)[lane] = z;
-            __syncthreads();
-            if (active && part == 0) {
-                z = 0.0;
-                for (int j = 0; j < P; ++j) z += s_z(wave + j)[lane];
-            }
-            __syncthreads();
-        }
-        if (active && part == 0) {
+        if (active) z = add_outside(z, cg, wB, a.NC);
+        if (active) {
             const double p = sigmoid(z + as_const(a.intercept)[c]);
             if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
         }
