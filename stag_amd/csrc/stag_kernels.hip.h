@@ -21,7 +21,10 @@
 namespace stagk {
 
 constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
-constexpr int NW = 4;             // waves per walk workgroup (all share the 64 staged rows)
+#ifndef STAG_NW
+#define STAG_NW 4
+#endif
+constexpr int NW = STAG_NW;             // waves per walk workgroup (all share the 64 staged rows)
 constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-byte sector of a row)
 constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
@@ -689,8 +692,13 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 uint32_t v[TILE / NW];
 #pragma unroll
                 for (int rr = 0; rr < TILE / NW; ++rr) {   // one row per wave and step, lanes over words
-                    const int s = __shfl(seq, rr * NW + wave);  // wave-uniform
-                    v[rr] = (s >= 0 && lane < width) ? a.bits[(size_t)s * a.W + w0 + lane] : 0u;
+                    // the row's sequence id as a scalar: its address is then computed once per wave
+                    const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+                    v[rr] = 0u;
+                    if (s >= 0) {
+                        const uint32_t *src = a.bits + ((size_t)s * a.W + w0);
+                        if (lane < width) v[rr] = src[lane];
+                    }
                 }
                 __syncthreads();  // everyone is done reading the previous slice
 #pragma unroll
