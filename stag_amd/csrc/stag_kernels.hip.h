@@ -683,9 +683,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             // this wave's coefficient range of the slice: contiguous, chunk after chunk
             uint32_t e_lo = 0, e_hi = 0;
             if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
-            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
             uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-            if (lane < ENT_PIECE && piece + lane < e_hi) ent = a.blocks[piece + lane];   // in flight together with the rows
+            if (lane < ENT_PIECE && e_lo + lane < e_hi) ent = a.blocks[e_lo + lane];   // in flight together with the rows
             if (!one_slice || pass0 == 0) {
                 const int w0 = sA * CHUNK_WORDS;
                 const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
@@ -712,23 +711,41 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
                                      (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-                for (int ch = sA; ch < sB; ++ch) {
-                    const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
-                    double cs = 0.0;
-                    for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                        if (e >= piece + ENT_PIECE) {   // rare: more than 48 coefficients in the slice
-                            piece = e;
-                            if (lane < ENT_PIECE)
-                                s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
+                if (e_hi - e_lo <= (uint32_t)ENT_PIECE) {
+                    // the usual case: every coefficient of the slice is in s_ent
+                    for (int ch = sA; ch < sB; ++ch) {
+                        const uint32_t e0 = bo[ch] * BLOCK_ENTRIES - e_lo, e1 = bo[ch + 1] * BLOCK_ENTRIES - e_lo;
+                        double cs = 0.0;
+                        for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                            const uint4 *pe = &s_ent[e];   // wave-uniform address: LDS broadcast
+                            const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                            cs += masked_weight_v(my_row, n0);
+                            cs += masked_weight_v(my_row, n1);
+                            cs += masked_weight_v(my_row, n2);
+                            cs += masked_weight_v(my_row, n3);
                         }
-                        const uint4 *pe = &s_ent[e - piece];   // wave-uniform address: LDS broadcast
-                        const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
-                        cs += masked_weight_v(my_row, n0);
-                        cs += masked_weight_v(my_row, n1);
-                        cs += masked_weight_v(my_row, n2);
-                        cs += masked_weight_v(my_row, n3);
+                        z += cs;
                     }
-                    z += cs;
+                } else {
+                    uint32_t piece = e_lo;   // first entry held in s_ent[wave]
+                    for (int ch = sA; ch < sB; ++ch) {
+                        const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
+                        double cs = 0.0;
+                        for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                            if (e >= piece + ENT_PIECE) {   // more than 48 coefficients in the slice: next piece
+                                piece = e;
+                                if (lane < ENT_PIECE)
+                                    s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
+                            }
+                            const uint4 *pe = &s_ent[e - piece];
+                            const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                            cs += masked_weight_v(my_row, n0);
+                            cs += masked_weight_v(my_row, n1);
+                            cs += masked_weight_v(my_row, n2);
+                            cs += masked_weight_v(my_row, n3);
+                        }
+                        z += cs;
+                    }
                 }
             }
         }
