@@ -559,8 +559,10 @@ __device__ __forceinline__ double add_outside(double z, const double STAG_CONST 
         for (int j = 0; j < 8; ++j) d[j] = cg[g + j];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
+            // the choice is made on the (wave-uniform) addend, in scalar registers: one v_add_f64
+            // per chunk.  Adding +0.0 changes nothing: z is never -0.0 (it starts at +0.0).
             const int ch = g + j;
-            if (ch >= lo && ch < hi) z += d[j];
+            z += (ch >= lo && ch < hi) ? d[j] : 0.0;
         }
     }
     return z;
