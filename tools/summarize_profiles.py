@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/final/ (written by tools/collect_profiles.sh on the GPU box) into the files
+committed under profiles/: the bench line, the rocprofv3 kernel-stats summary and the HBM traffic
+per launch (FETCH_SIZE doubled for gfx950 as /opt/skills/guides/MI355X_MICROARCH.md prescribes,
+plus WRITE_SIZE; both are reported by rocprofv3 in KiB)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "final")
+DST = os.path.join(ROOT, "profiles")
+tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+
+
+def short(name):
+    name = name.split("(")[0]
+    name = name.replace("void ", "").replace("stagk::", "")
+    return name.split("<")[0]
+
+
+def counter(dirname, cname):
+    f = glob.glob(os.path.join(SRC, dirname, "*", "*_counter_collection.csv"))[0]
+    tot, disp = collections.Counter(), collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] != cname:
+            continue
+        k = short(r["Kernel_Name"])
+        tot[k] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    return tot, {k: len(v) for k, v in disp.items()}
+
+
+shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench_final.json"))
+stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
+
+fetch, nf = counter("pmc_fetch", "FETCH_SIZE")
+write, nw = counter("pmc_write", "WRITE_SIZE")
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 0 "
+               "--no-cpu-baseline --check 0` (two passes over the C2 batch: the timed step and the event-profiled "
+               "step). Counter values are KiB as rocprofv3 reports them (x1024 -> bytes); FETCH_SIZE is doubled "
+               "for gfx950 as MI355X_MICROARCH.md (HBM section) prescribes, which over-counts kernels whose "
+               "reads are narrow. hbm_bytes_per_launch = (2*FETCH + WRITE) / dispatches.",
+       "kernels": {}}
+for k in fetch:
+    if not k.startswith("k_"):
+        continue
+    d = max(nf.get(k, 1), 1)
+    f = fetch[k] * 1024 / d
+    w = write.get(k, 0.0) * 1024 / max(nw.get(k, 1), 1)
+    out["kernels"][k] = {"dispatches": d, "FETCH_SIZE_bytes_raw": f, "WRITE_SIZE_bytes": w,
+                         "hbm_bytes_per_launch": 2 * f + w}
+json.dump(out, open(os.path.join(DST, tag + "_pmc_traffic.json"), "w"), indent=1)
+for k, v in out["kernels"].items():
+    print("%-16s %3d launches  %8.1f MB/launch" % (k, v["dispatches"], v["hbm_bytes_per_launch"] / 1e6))
