@@ -16,6 +16,8 @@ What is called from the reference (zellerlab/stag 0.8.2):
                                                              -> tsv.json
   stag.classify_genome.concat_alignments (classify_genome.py:364-388) -> concat.json
   stag.databases.save_to_file           (databases.py:111-147) -> tiny.stagDB (+ tiny_db.json)
+  stag.helpers.read_fasta               (helpers.py:107-121) and
+  stag.classify.alignment_reader        (classify.py:16-20)  -> ingest.json
 
 Only inputs and the reference's outputs are stored; no reference source enters the repo.
 Floats are stored through repr(), which round-trips float64 exactly.
@@ -34,6 +36,7 @@ import stag.align as ref_align            # noqa: E402
 import stag.classify as ref_classify      # noqa: E402
 import stag.classify_genome as ref_genome  # noqa: E402
 import stag.databases as ref_db           # noqa: E402
+import stag.helpers as ref_helpers        # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 os.makedirs(OUT, exist_ok=True)
@@ -417,7 +420,69 @@ def gen_stagdb():
         print("wrote tiny.stagDB", os.path.getsize(path), "bytes")
 
 
+def gen_ingest():
+    """read_fasta over byte streams and alignment_reader over -s files, with the awkward cases:
+    wrapped lines, trailing blanks, CRLF, headers without lines, text before the first header,
+    no newline at the end, non-ASCII whitespace, fields that are not plain 0/1."""
+    rng = np.random.default_rng(77)
+    fasta_cases = {
+        "plain": b">a\nACGT\n>b desc here\nAC\nGT\n",
+        "wrapped_blank_tail": b">r1  \nAC-gt  \n..TT\t\n\n>r2\nA\n",
+        "crlf": b">x\r\nAC\r\nGT\r\n>y\r\nTT\r\n",
+        "no_final_newline": b">a\nAC\n>b\nGG",
+        "header_without_lines": b">a\n>b\nAC\n>c\n>d\n",
+        "text_before_header": b"ACGT\nTT\n>a\nGG\n",
+        "empty_line_record": b">a\n\n>b\nAC\n",
+        "only_header": b">a\n",
+        "empty": b"",
+        "inner_spaces": b">a b\tc\nAC GT\n  leading\n",
+        "gt_inside": b">a\nAC>GT\n>b\n>\nAA\n",
+        "nbsp_tail": ">a\nAC\u00a0\n>b\u00a0\nGT\n".encode("utf-8"),
+        "unicode_id": ">s\u00e9q 1\nAC\n".encode("utf-8"),
+        "ctrl_ws": b">a\nAC\x1c\x1f\n\x0bGT\x0c\n",
+    }
+    big = []
+    for i in range(300):
+        seq = "".join(rng.choice(list("ACGT-acgt."), size=int(rng.integers(0, 200))))
+        lines = [seq[j:j + 60] for j in range(0, len(seq), 60)]
+        big.append(">read%d some text\n%s\n" % (i, "\n".join(lines)) if lines else ">read%d\n" % i)
+    fasta_cases["many_wrapped"] = "".join(big).encode("ascii")
+    fasta = {}
+    for name, data in fasta_cases.items():
+        got = list(ref_helpers.read_fasta(io.BytesIO(data), head_start=1))
+        fasta[name] = {"hex": data.hex(), "records": [[sid, seq] for sid, seq in got]}
+
+    onehot_cases = {
+        "plain": "a\t0\t1\t1\t0\t0\nb\t1\t0\t0\t0\t0\n",
+        "crlf_cr": "a\t0\t1\r\nb\t1\t0\rc\t1\t1\n",
+        "no_final_newline": "a\t0\t1\nb\t1\t1",
+        "trailing_tabs": "a\t0\t1\t\t\nb\t1\t0 \n",
+        "no_fields": "justid\n\n\t\n",
+        "empty_id": "\t1\t0\n",
+        "wide_ints": "a\t2\t-1\t0\t+1\t 1\n",
+        "ragged": "a\t0\t1\t1\nb\t1\nc\t1\t0\t1\t1\t0\t1\n",
+        "nbsp_tail": "a\t0\t1\u00a0\n",
+        "underscore": "a\t1_0\t0\n",
+    }
+    x = rng.random((40, 35)) < 0.4
+    onehot_cases["block_40x35"] = "".join("g%d\t%s\n" % (i, "\t".join("1" if v else "0" for v in row))
+                                          for i, row in enumerate(x))
+    onehot = {}
+    for name, text in onehot_cases.items():
+        with tempfile.NamedTemporaryFile("wb", suffix=".tsv", delete=False) as fh:
+            fh.write(text.encode("utf-8"))
+        try:
+            rows = [[gid, [int(v) for v in arr]] for gid, arr in ref_classify.alignment_reader(fh.name)]
+            err = None
+        except Exception as e:      # int() rejects a field: the reference raises
+            rows, err = None, type(e).__name__
+        os.remove(fh.name)
+        onehot[name] = {"hex": text.encode("utf-8").hex(), "rows": rows, "raises": err}
+    dump("ingest.json", {"fasta": fasta, "onehot": onehot})
+
+
 if __name__ == "__main__":
+    gen_ingest()
     gen_encode()
     gen_backtranslate()
     gen_classify_seq()

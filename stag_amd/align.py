@@ -11,8 +11,9 @@ import shlex
 import subprocess
 import sys
 
-from . import _lib
+from . import _lib, ingest
 from .helpers import is_tool, read_fasta
+from .tables import pack_text
 
 BATCH_RECORDS = 1 << 16      # records handed to the GPU at a time
 
@@ -33,9 +34,8 @@ def protein2gene_alignment(gene_id, protein_alignment, gene_sequence, check_leng
     return out.raw[:n.value].decode("latin-1")
 
 
-def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose):
-    """The part of align_generator (align.py:98-175) before the one-hot conversion: yields
-    (id, nucleotide-aligned string) and checks the tools' exit codes once the stream drains."""
+def _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose):
+    """align.py:116-141: tool checks and the hmmalign/cmalign | esl-reformat pipe."""
     if use_cmalign and not is_tool("cmalign"):
         raise ValueError("[E::align] Error: cmalign is not in the path. Please install Infernal.")
     elif not is_tool("hmmalign"):
@@ -50,7 +50,22 @@ def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
         print(f"Command used to align the sequences: {align_cmd}", file=sys.stderr)
     align_proc = subprocess.Popen(shlex.split(align_cmd), stdout=subprocess.PIPE)
     parse_proc = subprocess.Popen(shlex.split("esl-reformat a2m -"), stdin=align_proc.stdout, stdout=subprocess.PIPE)
+    return align_proc, parse_proc
 
+
+def _finish_aligner(align_proc, parse_proc):
+    align_proc.stdout.close()
+    if align_proc.wait():
+        raise ValueError("[E::align] Error. hmmalign/cmalign failed.")
+    parse_proc.stdout.close()
+    if parse_proc.wait():
+        raise ValueError("[E::align] Error. esl-reformat failed.")
+
+
+def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose):
+    """The part of align_generator (align.py:98-175) before the one-hot conversion: yields
+    (id, nucleotide-aligned string) and checks the tools' exit codes once the stream drains."""
+    align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
     if protein_file:
         gene_fh = open(seq_file)
         stream = zip(read_fasta(parse_proc.stdout, head_start=1), read_fasta(gene_fh, is_binary=False, head_start=1))
@@ -73,12 +88,23 @@ def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
     finally:
         if gene_fh:
             gene_fh.close()
-    align_proc.stdout.close()
-    if align_proc.wait():
-        raise ValueError("[E::align] Error. hmmalign/cmalign failed.")
-    parse_proc.stdout.close()
-    if parse_proc.wait():
-        raise ValueError("[E::align] Error. esl-reformat failed.")
+    _finish_aligner(align_proc, parse_proc)
+
+
+def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose, size=None):
+    """Batches (ids, text uint8, offs int64) of aligned records for Database.classify_a2m_text.
+    Nucleotide databases go from the pipe to the batch in C (stag_amd.ingest.fasta_batches: no
+    Python string per record); protein databases pair every record with its gene and
+    back-translate it first (align.py:155-160)."""
+    size = size or BATCH_RECORDS
+    if protein_file:
+        for ids, seqs in batched(aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose), size):
+            text, offs = pack_text(seqs)
+            yield ids, text, offs
+        return
+    align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
+    yield from ingest.fasta_batches(parse_proc.stdout, batch_records=size)
+    _finish_aligner(align_proc, parse_proc)
 
 
 def batched(records, size=BATCH_RECORDS):

@@ -16,10 +16,10 @@ import time
 import numpy as np
 
 from . import __version__ as tool_version
-from . import _lib, align, parallel
+from . import _lib, align, ingest, parallel
 from .databases import load_db
 from .engine import Database, raise_for_status
-from .tables import pack_db, unpack_rows
+from .tables import pack_db
 
 OUT_HEADER = ["sequence", "taxonomy", "full_taxonomy", "selected_level",
               "prob_from_classifiers", "prob_per_level", "n_aligned_characters"]
@@ -46,43 +46,22 @@ def alignment_reader(aligned_sequences):
 
 
 def _classify_prealigned(db, aligned_sequences, tagged, state):
-    """-s path: rows arrive already one-hot encoded (any bit pattern).  Under torchrun the
-    batches of the stream are dealt round-robin to the ranks (parallel.owner_of_batch)."""
+    """-s path: rows arrive already one-hot encoded (any bit pattern).  The file is parsed in C
+    (stag_amd.ingest.onehot_batches) straight into packed rows; lines it does not take literally
+    go through parse_onehot_line.  Under torchrun the batches of the stream are dealt round-robin
+    to the ranks (parallel.owner_of_batch)."""
     world, rank = parallel.world_rank()
-    ids, X = [], []
-    batch = [0]
-
-    def flush():
-        b = batch[0]
-        batch[0] += 1
-        if not ids or parallel.owner_of_batch(b, world) != rank:
-            ids.clear()
-            X.clear()
-            return
-        L = db.n_features
-        good = np.array([len(x) == L for x in X])
-        M = np.zeros((len(X), L), dtype=bool)
-        for i, x in enumerate(X):
-            if good[i]:
-                M[i] = x
-        res = db.classify_bits(_pack(M, db), np.where(good, _lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH).astype(np.int32))
-        tagged.append((b, db.result_rows(res, ids, long_out=True)))
-        ids.clear()
-        X.clear()
-
-    for gene_id, ali in alignment_reader(aligned_sequences):
+    L = db.n_features
+    batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
+                                    slow_line=parse_onehot_line)
+    for b, (ids, bits, n_fields) in enumerate(batches):
         if not state["alignment_length"]:
-            state["alignment_length"] = len(ali)
-        ids.append(gene_id)
-        X.append(ali)
-        if len(ids) >= READER_BATCH:
-            flush()
-    flush()
-
-
-def _pack(M, db):
-    from .tables import pack_bool_rows
-    return pack_bool_rows(M, db.words_per_row)
+            state["alignment_length"] = int(n_fields[0])
+        if parallel.owner_of_batch(b, world) != rank:
+            continue
+        status = np.where(n_fields == L, _lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH).astype(np.int32)
+        res = db.classify_bits(bits, status)
+        tagged.append((b, db.result_rows(res, ids, long_out=True)))
 
 
 def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, threads=1, output=None,
@@ -107,16 +86,16 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
         if aligned_sequences:
             _classify_prealigned(db, aligned_sequences, tagged, state)
         else:
-            records = align.aligned_records(fasta_input, protein_fasta_input, hmm_file_path, use_cmalign,
+            batches = align.aligned_batches(fasta_input, protein_fasta_input, hmm_file_path, use_cmalign,
                                             threads, verbose)
-            alignment_out = open(save_ali_to_file, "w") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
+            alignment_out = open(save_ali_to_file, "wb") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
             with alignment_out:
-                for b, (ids, seqs) in enumerate(align.batched(records)):
+                for b, (ids, text, offs) in enumerate(batches):
                     mine = parallel.owner_of_batch(b, world) == rank
                     if not mine and not (save_ali_to_file and rank == 0) and state["alignment_length"]:
                         continue
-                    res = db.classify_a2m(seqs, min_perc_state=min_perc_state,
-                                          want_bits=bool(save_ali_to_file) and rank == 0)
+                    res = db.classify_a2m_text(text, offs, min_perc_state=min_perc_state,
+                                               want_bits=bool(save_ali_to_file) and rank == 0)
                     raise_for_status(res.status, ids)
                     passed = np.flatnonzero(res.status == _lib.SEQ_OK)
                     n_pass += len(passed)
@@ -125,10 +104,9 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                         state["alignment_length"] = 5 * int(res.n_char[passed[0]])
                     if mine:
                         tagged.append((b, db.result_rows(res, ids, long_out=True)))
-                    if save_ali_to_file and rank == 0 and len(passed):
-                        dense = unpack_rows(res.bits[passed], db.n_features)
-                        for i, x in zip(passed, dense):       # classify.py:160-162
-                            print(ids[i], "\t".join(np.where(x, "1", "0")), sep="\t", file=alignment_out)
+                    if save_ali_to_file and rank == 0 and len(passed):      # classify.py:160-162
+                        alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed],
+                                                                 db.n_features))
             if verbose > 3 and world == 1:
                 print(f" Number of sequences that pass the filter: {n_pass}", file=sys.stderr)
                 print(f" Number of sequences that do not pass the filter: {n_not_pass}", file=sys.stderr)

@@ -1,0 +1,180 @@
+/* libstag_ingest.so: include/stag_ingest.h.  Host-only C; no allocation, no global state. */
+#include "stag_ingest.h"
+
+#include <string.h>
+
+/* what str.rstrip() removes among ASCII bytes: \t \n \v \f \r, FS GS RS US, space */
+static inline int ascii_space(unsigned char c) { return (c >= 0x09 && c <= 0x0d) || (c >= 0x1c && c <= 0x20); }
+
+/* end of the line's content after rstrip; *fallback set when the content ends in a non-ASCII byte
+ * (U+0085, U+00A0 ... are whitespace for Python too: let the caller's slow path decide) */
+static inline int64_t rstrip_end(const char *buf, int64_t b, int64_t e, int *fallback) {
+    while (e > b && ascii_space((unsigned char)buf[e - 1])) --e;
+    if (e > b && ((unsigned char)buf[e - 1] & 0x80)) *fallback = 1;
+    return e;
+}
+
+int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_start, int64_t max_records,
+                        char *text_out, int64_t text_cap, int64_t text_used_in, int64_t *offs,
+                        stag_record_t *recs, int64_t *consumed, int64_t *text_used) {
+    if (!buf || len < 0 || max_records < 0 || !text_out || !offs || !recs || !consumed || !text_used ||
+        text_used_in < 0 || text_cap - text_used_in < len)
+        return -1;
+    int64_t n = 0, pos = 0, used = text_used_in;
+    offs[0] = used;
+    *consumed = 0;
+    /* the open record */
+    int open = 0, fb = 0;
+    int64_t r_begin = 0, r_id = 0, r_idlen = -1, r_lines = 0, r_text = used;
+
+    while (pos < len) {
+        const char *nl = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
+        if (!nl && !final) break;   /* incomplete line: wait for more bytes */
+        const int64_t line_end = nl ? (int64_t)(nl - buf) : len;
+        const int64_t next = nl ? line_end + 1 : len;
+        if (buf[pos] == '>') {
+            if (open) {   /* the previous record ends where this header begins */
+                if (r_lines > 0) {
+                    recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = pos;
+                    recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
+                    offs[++n] = used;
+                } else {
+                    used = r_text;
+                }
+                open = 0;
+                *consumed = pos;
+                if (n >= max_records) { *text_used = used; return n; }
+            }
+            fb = 0;
+            const int64_t e = rstrip_end(buf, pos, line_end, &fb);
+            open = 1;
+            r_begin = pos; r_id = pos + 1; r_idlen = e - (pos + 1); r_lines = 0; r_text = used;
+        } else {
+            if (!open) {
+                if (!at_start || *consumed != 0 || n != 0) return -1;   /* every later chunk starts at a header */
+                open = 1; fb = 0;
+                r_begin = pos; r_id = pos; r_idlen = -1; r_lines = 0; r_text = used;
+            }
+            const int64_t e = rstrip_end(buf, pos, line_end, &fb);
+            unsigned char hi = 0;   /* a non-ASCII character is ONE column for the reference, not one per byte */
+            for (int64_t i = pos; i < e; ++i) {
+                const unsigned char c = (unsigned char)buf[i];
+                text_out[used + (i - pos)] = (char)c;
+                hi |= c;
+            }
+            if (hi & 0x80) fb = 1;
+            used += e - pos;
+            ++r_lines;
+        }
+        pos = next;
+    }
+    if (final && pos >= len && open) {
+        if (r_lines > 0 && n < max_records) {
+            recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = len;
+            recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
+            offs[++n] = used;
+            *consumed = len;
+        } else if (r_lines == 0) {
+            used = r_text;
+            *consumed = len;
+        } else {
+            used = r_text;   /* no room for it: the caller calls again */
+        }
+    } else if (open) {
+        used = r_text;       /* incomplete record: its lines are re-read next time */
+    }
+    if (final && !open && pos >= len) *consumed = len;
+    *text_used = used;
+    return n;
+}
+
+int64_t stag_onehot_parse(const char *buf, int64_t len, int32_t final, int32_t n_features, int32_t words_per_row,
+                          int64_t max_rows, uint32_t *bits_out, stag_record_t *recs, int64_t *consumed) {
+    if (!buf || len < 0 || max_rows < 0 || !bits_out || !recs || !consumed || n_features < 0 ||
+        (int64_t)words_per_row * 32 < n_features)
+        return -1;
+    int64_t n = 0, pos = 0;
+    *consumed = 0;
+    while (pos < len && n < max_rows) {
+        /* universal newlines: the line ends at the first '\n' or '\r' */
+        const char *a = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
+        const int64_t lim = a ? (int64_t)(a - buf) : len;
+        const char *b = (const char *)memchr(buf + pos, '\r', (size_t)(lim - pos));
+        const int64_t e = b ? (int64_t)(b - buf) : lim;
+        int64_t next;
+        if (e >= len) {
+            if (!final) break;
+            next = len;
+        } else if (buf[e] == '\r') {
+            if (e + 1 < len) next = buf[e + 1] == '\n' ? e + 2 : e + 1;
+            else if (final) next = len;
+            else break;   /* a '\n' may still follow */
+        } else {
+            next = e + 1;
+        }
+        int fb = 0;
+        const int64_t le = rstrip_end(buf, pos, e, &fb);
+        stag_record_t *r = &recs[n];
+        r->raw_begin = pos; r->raw_end = next; r->pad = 0;
+        const char *tab = (const char *)memchr(buf + pos, '\t', (size_t)(le - pos));
+        const int64_t id_end = tab ? (int64_t)(tab - buf) : le;
+        r->id_begin = pos; r->id_len = id_end - pos;
+        uint32_t *row = bits_out + (size_t)n * words_per_row;
+        memset(row, 0, (size_t)words_per_row * sizeof(uint32_t));
+        int64_t nf = 0;
+        if (tab) {
+            const int64_t body = id_end + 1, blen = le - body;   /* "x\tx\t...x": blen = 2 nf - 1 */
+            if (blen <= 0 || (blen & 1) == 0) {
+                fb = 1;
+            } else {
+                nf = (blen + 1) / 2;
+                const unsigned char *p = (const unsigned char *)buf + body;
+                unsigned bad = 0;
+                if (nf == n_features) {
+                    for (int64_t w = 0; w * 32 < nf; ++w) {
+                        const int64_t f0 = w * 32, f1 = f0 + 32 < nf ? f0 + 32 : nf;
+                        uint32_t v = 0;
+                        for (int64_t f = f0; f < f1; ++f) {
+                            const unsigned c = p[2 * f];
+                            bad |= (c & 0xfeu) ^ 0x30u;            /* '0' or '1' */
+                            v |= (uint32_t)(c & 1u) << (f - f0);
+                        }
+                        row[w] = v;
+                    }
+                } else {
+                    for (int64_t f = 0; f < nf; ++f) bad |= (p[2 * f] & 0xfeu) ^ 0x30u;
+                }
+                for (int64_t f = 0; f + 1 < nf; ++f) bad |= p[2 * f + 1] ^ (unsigned)'\t';
+                if (bad) { fb = 1; memset(row, 0, (size_t)words_per_row * sizeof(uint32_t)); }
+            }
+        }
+        r->n_fields = nf;
+        r->flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK;
+        ++n;
+        pos = next;
+        *consumed = pos;
+    }
+    return n;
+}
+
+int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, int32_t words_per_row,
+                           const char *ids, const int64_t *id_off, char *out, int64_t out_cap) {
+    if (!bits || n < 0 || n_features < 0 || !ids || !id_off || (!out && out_cap > 0)) return -1;
+    int64_t need = 0;
+    for (int64_t i = 0; i < n; ++i) need += (id_off[i + 1] - id_off[i]) + 1 + (n_features ? 2 * (int64_t)n_features - 1 : 0) + 1;
+    if (need > out_cap) return -need;
+    char *o = out;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t il = id_off[i + 1] - id_off[i];
+        memcpy(o, ids + id_off[i], (size_t)il);
+        o += il;
+        *o++ = '\t';   /* print(id, "", sep="\t") also writes the separator when there are no features */
+        const uint32_t *row = bits + (size_t)i * words_per_row;
+        for (int32_t f = 0; f < n_features; ++f) {
+            *o++ = (char)('0' + ((row[f >> 5] >> (f & 31)) & 1u));
+            if (f + 1 < n_features) *o++ = '\t';
+        }
+        *o++ = '\n';
+    }
+    return (int64_t)(o - out);
+}

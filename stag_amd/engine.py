@@ -144,7 +144,18 @@ class Database:
     def classify_a2m(self, strings, min_perc_state=0.0, want_bits=False):
         """encode + classify on the GPU; rows never leave it unless want_bits."""
         text, offs = pack_text(strings)
-        n = len(strings)
+        return self.classify_a2m_text(text, offs, min_perc_state, want_bits)
+
+    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False):
+        """Same for records already laid out back to back: record i = text[offs[i]:offs[i+1]]
+        (uint8, int64[n+1]); what stag_amd.ingest.fasta_batches produces."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        n = len(offs) - 1
+        if n < 0 or (n > 0 and (offs[0] < 0 or offs[-1] > len(text))):
+            raise ValueError("offs does not describe records inside text")
+        if len(text) == 0:
+            text = np.zeros(16, dtype=np.uint8)
         res = BatchResult(n, self.max_depth, self.n_keys)
         st = res.as_struct()
         res.n_char = np.zeros(n, dtype=np.int32)

@@ -1,0 +1,188 @@
+"""Host ingestion around the GPU path: native parsers for the two text
+formats that feed it and the writer for the one it emits, bound from libstag_ingest.so
+(include/stag_ingest.h, plain C, no GPU).
+
+  fasta_batches   stag/helpers.py:107-121 read_fasta over the `esl-reformat a2m -` pipe
+                  (stag/align.py:139-147) -> (ids, text uint8, offs int64) batches ready for
+                  stag_classify_a2m: no Python string per record
+  onehot_batches  stag/classify.py:16-20 alignment_reader -> (ids, packed rows, n_fields) batches
+  format_onehot   stag/classify.py:160-162, the -S lines
+
+Records the C fast path cannot reproduce byte for byte are flagged by it and re-parsed here the
+way the reference does (Python str methods), so the output is the reference's in every case.
+"""
+import ctypes
+import io
+import os
+
+import numpy as np
+
+from .helpers import read_fasta
+from .tables import pack_text
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstag_ingest.so")
+FALLBACK = 1
+
+c_p = ctypes.c_void_p
+RECORD = np.dtype([("id_begin", "<i8"), ("id_len", "<i8"), ("raw_begin", "<i8"), ("raw_end", "<i8"),
+                   ("n_fields", "<i8"), ("flag", "<i4"), ("pad", "<i4")])
+
+EXPORTS = {
+    "stag_fasta_scan": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                         c_p, ctypes.c_int64, ctypes.c_int64, c_p, c_p, c_p, c_p]),
+    "stag_onehot_parse": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
+                                           ctypes.c_int64, c_p, c_p, c_p]),
+    "stag_onehot_format": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_p, c_p, c_p,
+                                            ctypes.c_int64]),
+}
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("%s is missing: build it with `make -C stag_amd/csrc`" % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in EXPORTS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(c_p)
+
+
+def _chunks(stream, chunk_bytes):
+    """(bytes, final) pieces of a binary stream; the last piece (possibly empty) has final=True."""
+    cur = stream.read(chunk_bytes)
+    while True:
+        nxt = stream.read(chunk_bytes) if cur else b""
+        yield cur, not nxt
+        if not nxt:
+            return
+        cur = nxt
+
+
+def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1):
+    """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
+    (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
+    (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1)."""
+    L = lib()
+    pending = b""
+    at_start = True
+    ids, texts, offs_parts, total = [], [], [np.zeros(1, dtype=np.int64)], 0
+
+    def flush():
+        nonlocal ids, texts, offs_parts, total
+        text = np.concatenate(texts) if texts else np.zeros(0, dtype=np.uint8)
+        text = np.concatenate([text, np.zeros(-len(text) % 16, dtype=np.uint8)])
+        out = (ids, text, np.concatenate(offs_parts))
+        ids, texts, offs_parts, total = [], [], [np.zeros(1, dtype=np.int64)], 0
+        return out
+
+    for piece, final in _chunks(stream, chunk_bytes):
+        buf = pending + piece
+        pos = 0
+        while True:
+            view = np.frombuffer(buf, dtype=np.uint8)[pos:]
+            room = batch_records - len(ids)
+            text = np.empty(max(len(view), 1), dtype=np.uint8)
+            offs = np.zeros(room + 1, dtype=np.int64)
+            recs = np.zeros(max(room, 1), dtype=RECORD)
+            consumed, used = ctypes.c_int64(0), ctypes.c_int64(0)
+            n = L.stag_fasta_scan(_ptr(view) if len(view) else _ptr(text), len(view), int(final), int(at_start), room,
+                                  _ptr(text), len(text), 0, _ptr(offs), _ptr(recs), ctypes.byref(consumed),
+                                  ctypes.byref(used))
+            if n < 0:
+                raise ValueError("malformed FASTA/A2M stream (a record does not start with '>')")
+            recs = recs[:n]
+            if n and (recs["flag"] == FALLBACK).any():
+                # non-ASCII bytes at a line end: let Python's str.rstrip decide, as the reference does
+                raw = bytes(view[int(recs["raw_begin"][0]):int(recs["raw_end"][-1])])
+                pairs = list(read_fasta(io.BytesIO(raw), head_start=head_start))
+                t, o = pack_text([s for _, s in pairs])
+                ids.extend(sid for sid, _ in pairs)
+                texts.append(t[:int(o[-1])])
+                offs_parts.append(o[1:] + total)
+                total += int(o[-1])
+            elif n:
+                for r in recs:
+                    if r["id_len"] < 0:
+                        ids.append(None)
+                    else:
+                        b = pos + int(r["id_begin"]) - 1 + head_start
+                        ids.append(buf[b:pos + int(r["id_begin"]) + int(r["id_len"])].decode("utf-8"))
+                texts.append(text[:used.value])
+                offs_parts.append(offs[1:n + 1] + total)
+                total += used.value
+            if consumed.value:
+                at_start = False
+            pos += consumed.value
+            if len(ids) >= batch_records:
+                yield flush()
+                continue          # more records may be waiting in this buffer
+            break
+        pending = buf[pos:]
+    if ids:
+        yield flush()
+
+
+def onehot_batches(path, n_features, words_per_row, batch_rows=1 << 14, chunk_bytes=1 << 26, slow_line=None):
+    """Yields (ids, bits uint32 [n, words_per_row], n_fields int64 [n]) for the lines of a -s file.
+    Rows whose field count differs from n_features come back zero with their count.  Lines the
+    fast path does not accept go through `slow_line(str) -> (id, bool array)` (the reference's
+    int() per field)."""
+    L = lib()
+    pending = b""
+    with open(path, "rb") as fh:
+        for piece, final in _chunks(fh, chunk_bytes):
+            buf = pending + piece
+            pos = 0
+            while True:
+                view = np.frombuffer(buf, dtype=np.uint8)[pos:]
+                bits = np.zeros((batch_rows, words_per_row), dtype=np.uint32)
+                recs = np.zeros(batch_rows, dtype=RECORD)
+                consumed = ctypes.c_int64(0)
+                n = L.stag_onehot_parse(_ptr(view) if len(view) else _ptr(bits), len(view), int(final), n_features,
+                                        words_per_row, batch_rows, _ptr(bits), _ptr(recs), ctypes.byref(consumed))
+                if n < 0:
+                    raise ValueError("stag_onehot_parse: bad arguments")
+                if n == 0:
+                    break
+                recs, bits = recs[:n], bits[:n]
+                ids = [buf[pos + int(r["id_begin"]):pos + int(r["id_begin"]) + int(r["id_len"])].decode("utf-8")
+                       for r in recs]
+                n_fields = recs["n_fields"].copy()
+                for i in np.flatnonzero(recs["flag"] == FALLBACK):
+                    line = buf[pos + int(recs["raw_begin"][i]):pos + int(recs["raw_end"][i])].decode("utf-8")
+                    gid, x = slow_line(line)
+                    ids[i] = gid
+                    n_fields[i] = len(x)
+                    bits[i] = 0
+                    if len(x) == n_features:
+                        from .tables import pack_bool_rows
+                        bits[i] = pack_bool_rows(np.asarray(x, dtype=bool)[None, :], words_per_row)[0]
+                yield ids, bits, n_fields
+                pos += consumed.value
+            pending = buf[pos:]
+
+
+def format_onehot(ids, bits, n_features):
+    """The -S lines (classify.py:160-162) for packed rows, as bytes."""
+    bits = np.ascontiguousarray(bits, dtype=np.uint32)
+    n = len(ids)
+    enc = [s.encode("utf-8") for s in ids]
+    id_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=id_off[1:])
+    blob = np.frombuffer(b"".join(enc) + b"\0", dtype=np.uint8)
+    cap = int(id_off[-1]) + n * (2 * n_features + 2)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    w = bits.shape[1] if bits.ndim == 2 else 0
+    m = lib().stag_onehot_format(_ptr(bits), n, n_features, w, _ptr(blob), _ptr(id_off), _ptr(out), cap)
+    if m < 0:
+        raise RuntimeError("stag_onehot_format: buffer too small (%d)" % -m)
+    return out[:m].tobytes()

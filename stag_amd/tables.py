@@ -127,6 +127,11 @@ def pack_db(taxonomy, tax_function, classifiers, n_features=None):
     return PackedTables(names, child_first, row_kind, intercept, row_off, row_feat, row_w, keys, tf, L)
 
 
+def words_per_row(n_features):
+    """uint32 words of one packed row: stag_words_per_row of include/stag_hip.h (multiple of 4, >= 4)."""
+    return max(((n_features + 31) // 32 + 3) // 4 * 4, 4)
+
+
 def pack_text(strings):
     """list[str] -> (uint8 text buffer, int64 offsets[n+1]) for the *_a2m entry points."""
     raw = [s.encode("latin-1", "replace") if isinstance(s, str) else bytes(s) for s in strings]

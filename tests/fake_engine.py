@@ -40,6 +40,10 @@ class OracleDatabase(Database):
             res.status[bad] = np.asarray(status_in)[bad]
         return res
 
+    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False):
+        strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(len(offs) - 1)]
+        return self.classify_a2m(strings, min_perc_state, want_bits)
+
     def classify_a2m(self, strings, min_perc_state=0.0, want_bits=False):
         from stag_amd.tables import pack_bool_rows
         n = len(strings)

@@ -80,6 +80,44 @@ def test_classify_verbose_and_errors(fake_gpu, monkeypatch, tmp_path, capsys):
     assert ret == (None, []) and open(tmp_path / "o3").read() == "sequence\ttaxonomy\n"
 
 
+def test_classify_from_aligner_pipe_with_fake_tools(fake_gpu, monkeypatch, tmp_path):
+    """fasta_input path: hmmalign | esl-reformat (stand-in scripts that replay a prepared A2M
+    stream) -> native FASTA scanner -> encode + classify -> rows, and the -S file.  Expected
+    values are the reference's own output for the same rows through -s (tsv.json)."""
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)
+    sym = "-TGCA"
+    records = []
+    for k, line in enumerate(g["ali_lines"]):
+        gid, *f = line.split("\t")
+        x = np.array(f, dtype=int).reshape(-1, 5)
+        s = "".join(sym[int(np.argmax(col))] for col in x)
+        s = s[:5] + "acg"[:k % 4] + s[5:]                  # lowercase inserts are dropped (align.py:47)
+        wrapped = "\n".join(s[i:i + 7] for i in range(0, len(s), 7))
+        records.append(">%s\n%s\n" % (gid, wrapped))
+    a2m = tmp_path / "replay.a2m"
+    a2m.write_text("".join(records))
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s\n" % a2m)
+    (bindir / "esl-reformat").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat\n")
+    for t in ("hmmalign", "esl-reformat"):
+        os.chmod(bindir / t, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    fasta = tmp_path / "reads.fasta"
+    fasta.write_text(">unused\nACGT\n")
+    saved = tmp_path / "saved.tsv"
+    out = tmp_path / "o.tsv"
+    ret = sc.classify("db", fasta_input=str(fasta), output=str(out), verbose=1, save_ali_to_file=str(saved))
+    assert open(out).read() == g["runs"]["short"]["file"]
+    assert ret[0] == g["runs"]["short"]["return_len"] and ret[1] == g["runs"]["short"]["return_rows"]
+    assert saved.read_text() == "\n".join(g["ali_lines"]) + "\n"
+    assert saved.read_text().splitlines(True)[0] == g["save_ali_line"]
+    # a failing aligner is reported as in align.py:170
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s\nexit 3\n" % a2m)
+    with pytest.raises(ValueError, match="hmmalign/cmalign failed"):
+        sc.classify("db", fasta_input=str(fasta), output=str(tmp_path / "o2"), verbose=1)
+
+
 def test_parse_onehot_line_matches_reference_reader():
     for line in ("id1\t0\t1\t0\t0\t1\n", "id2\t0\t10\t0\t-3\t1\n", "id3\t1\n", "x y\t0\t0\n"):
         gid, x = sc.parse_onehot_line(line)

@@ -1,0 +1,127 @@
+"""libstag_ingest.so (include/stag_ingest.h) against the reference's own readers.
+
+tests/golden/ingest.json holds byte streams and what stag.helpers.read_fasta (helpers.py:107-121)
+and stag.classify.alignment_reader (classify.py:16-20) returned for them (oracle/make_golden.py).
+Every case is pushed through the native parsers at several chunk sizes, so record, line and
+"\r\n" boundaries fall on chunk edges.  No GPU involved.
+"""
+import ctypes
+import io
+
+import numpy as np
+import pytest
+
+from golden_util import load
+from stag_amd import ingest
+from stag_amd.classify import parse_onehot_line
+from stag_amd.tables import pack_bool_rows, unpack_rows, words_per_row
+
+G = load("ingest.json")
+
+
+def test_library_exports_every_declared_symbol():
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "stag_ingest.h")).read()
+    declared = set(re.findall(r"\b(stag_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(ingest.EXPORTS)
+    L = ingest.lib()
+    for name in declared:
+        assert hasattr(L, name)
+    assert ingest.RECORD.itemsize == 48
+
+
+def records_of(batches):
+    out = []
+    for ids, text, offs in batches:
+        assert len(text) % 16 == 0 and len(offs) == len(ids) + 1
+        for i, sid in enumerate(ids):
+            out.append([sid, bytes(text[offs[i]:offs[i + 1]]).decode("utf-8")])
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(G["fasta"]))
+@pytest.mark.parametrize("chunk", [1, 2, 3, 7, 64, 1 << 20])
+def test_fasta_scan_matches_reference(name, chunk):
+    case = G["fasta"][name]
+    data = bytes.fromhex(case["hex"])
+    got = records_of(ingest.fasta_batches(io.BytesIO(data), batch_records=1 << 16, chunk_bytes=chunk))
+    assert got == case["records"]
+
+
+@pytest.mark.parametrize("batch", [1, 2, 5, 299, 300, 301])
+def test_fasta_scan_batch_limits(batch):
+    case = G["fasta"]["many_wrapped"]
+    data = bytes.fromhex(case["hex"])
+    batches = list(ingest.fasta_batches(io.BytesIO(data), batch_records=batch, chunk_bytes=997))
+    assert all(len(b[0]) <= batch for b in batches)
+    assert records_of(batches) == case["records"]
+
+
+def rows_of(path, L, chunk, batch_rows=7):
+    W = words_per_row(L)
+    out = []
+    for ids, bits, n_fields in ingest.onehot_batches(path, L, W, batch_rows=batch_rows, chunk_bytes=chunk,
+                                                     slow_line=parse_onehot_line):
+        dense = unpack_rows(bits, L)
+        for i, gid in enumerate(ids):
+            out.append((gid, int(n_fields[i]), dense[i].astype(int).tolist() if n_fields[i] == L else None))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(G["onehot"]))
+@pytest.mark.parametrize("chunk", [1, 2, 5, 64, 1 << 20])
+def test_onehot_parse_matches_reference(tmp_path, name, chunk):
+    case = G["onehot"][name]
+    path = tmp_path / "in.tsv"
+    path.write_bytes(bytes.fromhex(case["hex"]))
+    if case["raises"]:
+        with pytest.raises(ValueError):      # int() on a field that is not an integer
+            rows_of(str(path), 3, chunk)
+        return
+    ref = case["rows"]
+    for L in sorted({len(r[1]) for r in ref} | {3}):
+        got = rows_of(str(path), L, chunk)
+        assert [g[0] for g in got] == [r[0] for r in ref]
+        assert [g[1] for g in got] == [len(r[1]) for r in ref]
+        for g, r in zip(got, ref):
+            if len(r[1]) == L:
+                assert g[2] == [int(bool(v)) for v in r[1]]
+
+
+def test_onehot_format_is_the_reference_S_line():
+    rng = np.random.default_rng(5)
+    for L in (0, 1, 5, 32, 33, 160, 7500):
+        X = rng.random((9, L)) < 0.3
+        ids = ["g%d" % i for i in range(8)] + ["sé q"]
+        W = max(words_per_row(L), 4)
+        bits = pack_bool_rows(X, W) if L else np.zeros((9, W), dtype=np.uint32)
+        want = io.StringIO()
+        for gid, x in zip(ids, X):          # classify.py:160-162
+            print(gid, "\t".join(np.where(x, "1", "0")), sep="\t", file=want)
+        assert ingest.format_onehot(ids, bits, L).decode("utf-8") == want.getvalue()
+
+
+def test_roundtrip_format_then_parse(tmp_path):
+    rng = np.random.default_rng(6)
+    L = 7500
+    X = rng.random((50, L)) < 0.2
+    ids = ["read_%d" % i for i in range(50)]
+    W = words_per_row(L)
+    bits = pack_bool_rows(X, W)
+    path = tmp_path / "s.tsv"
+    path.write_bytes(ingest.format_onehot(ids, bits, L))
+    got_ids, got_bits = [], []
+    for i, b, nf in ingest.onehot_batches(str(path), L, W, batch_rows=16, chunk_bytes=100_000, slow_line=parse_onehot_line):
+        assert (nf == L).all()
+        got_ids += i
+        got_bits.append(b)
+    assert got_ids == ids
+    assert (np.concatenate(got_bits) == bits).all()
+
+
+def test_bad_arguments_are_rejected():
+    L = ingest.lib()
+    c = ctypes.c_int64(0)
+    assert L.stag_onehot_parse(None, 0, 1, 5, 4, 1, None, None, ctypes.byref(c)) == -1
+    assert L.stag_fasta_scan(None, 0, 1, 1, 1, None, 0, 0, None, None, ctypes.byref(c), ctypes.byref(c)) == -1
