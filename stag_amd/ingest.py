@@ -67,56 +67,71 @@ def _chunks(stream, chunk_bytes):
         cur = nxt
 
 
+def _fill(stream, buf, have):
+    """Reads into buf[have:] until it is full or the stream ends; returns (bytes held, at end)."""
+    mv = memoryview(buf)
+    while have < len(buf):
+        got = stream.readinto(mv[have:])
+        if not got:
+            return have, True
+        have += got
+    return have, False
+
+
 def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1):
     """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
     (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1)."""
     L = lib()
-    pending = b""
-    at_start = True
+    buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
+    scratch = np.empty(len(buf), dtype=np.uint8)
+    have, at_start, ended = 0, True, False
     ids, texts, offs_parts, total = [], [], [np.zeros(1, dtype=np.int64)], 0
 
     def flush():
         nonlocal ids, texts, offs_parts, total
-        text = np.concatenate(texts) if texts else np.zeros(0, dtype=np.uint8)
-        text = np.concatenate([text, np.zeros(-len(text) % 16, dtype=np.uint8)])
+        text = np.zeros(total + (-total % 16), dtype=np.uint8)
+        at = 0
+        for t in texts:
+            text[at:at + len(t)] = t
+            at += len(t)
         out = (ids, text, np.concatenate(offs_parts))
         ids, texts, offs_parts, total = [], [], [np.zeros(1, dtype=np.int64)], 0
         return out
 
-    for piece, final in _chunks(stream, chunk_bytes):
-        buf = pending + piece
+    while not ended:
+        have, ended = _fill(stream, buf, have)
+        if len(scratch) < len(buf):
+            scratch = np.empty(len(buf), dtype=np.uint8)
         pos = 0
         while True:
-            view = np.frombuffer(buf, dtype=np.uint8)[pos:]
+            view = np.frombuffer(buf, dtype=np.uint8)[pos:have]
             room = batch_records - len(ids)
-            text = np.empty(max(len(view), 1), dtype=np.uint8)
             offs = np.zeros(room + 1, dtype=np.int64)
             recs = np.zeros(max(room, 1), dtype=RECORD)
             consumed, used = ctypes.c_int64(0), ctypes.c_int64(0)
-            n = L.stag_fasta_scan(_ptr(view) if len(view) else _ptr(text), len(view), int(final), int(at_start), room,
-                                  _ptr(text), len(text), 0, _ptr(offs), _ptr(recs), ctypes.byref(consumed),
+            n = L.stag_fasta_scan(_ptr(view) if len(view) else _ptr(scratch), len(view), int(ended), int(at_start), room,
+                                  _ptr(scratch), len(scratch), 0, _ptr(offs), _ptr(recs), ctypes.byref(consumed),
                                   ctypes.byref(used))
             if n < 0:
                 raise ValueError("malformed FASTA/A2M stream (a record does not start with '>')")
             recs = recs[:n]
             if n and (recs["flag"] == FALLBACK).any():
-                # non-ASCII bytes at a line end: let Python's str.rstrip decide, as the reference does
+                # non-ASCII bytes in a line: let Python's str methods decide, as the reference does
                 raw = bytes(view[int(recs["raw_begin"][0]):int(recs["raw_end"][-1])])
                 pairs = list(read_fasta(io.BytesIO(raw), head_start=head_start))
                 t, o = pack_text([s for _, s in pairs])
                 ids.extend(sid for sid, _ in pairs)
-                texts.append(t[:int(o[-1])])
+                texts.append(t[:int(o[-1])].copy())
                 offs_parts.append(o[1:] + total)
                 total += int(o[-1])
             elif n:
-                for r in recs:
-                    if r["id_len"] < 0:
-                        ids.append(None)
-                    else:
-                        b = pos + int(r["id_begin"]) - 1 + head_start
-                        ids.append(buf[b:pos + int(r["id_begin"]) + int(r["id_len"])].decode("utf-8"))
-                texts.append(text[:used.value])
+                begins = (recs["id_begin"] + (pos - 1 + head_start)).tolist()
+                ends = (recs["id_begin"] + recs["id_len"] + pos).tolist()
+                ids.extend([bytes(buf[b:e]).decode("utf-8") for b, e in zip(begins, ends)])
+                if recs["id_len"][0] < 0:          # lines before the first header: sid is None
+                    ids[len(ids) - n] = None
+                texts.append(scratch[:used.value].copy())
                 offs_parts.append(offs[1:n + 1] + total)
                 total += used.value
             if consumed.value:
@@ -126,7 +141,14 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
                 yield flush()
                 continue          # more records may be waiting in this buffer
             break
-        pending = buf[pos:]
+        # keep the unparsed tail; a record longer than the buffer makes the buffer grow
+        rest = have - pos
+        if pos == 0 and have == len(buf) and not ended:
+            buf = buf + bytearray(len(buf))      # a new object: NumPy views of the old one may be alive
+        elif pos:
+            view = None
+            buf[:rest] = buf[pos:have]
+        have = rest
     if ids:
         yield flush()
 
@@ -154,8 +176,9 @@ def onehot_batches(path, n_features, words_per_row, batch_rows=1 << 14, chunk_by
                 if n == 0:
                     break
                 recs, bits = recs[:n], bits[:n]
-                ids = [buf[pos + int(r["id_begin"]):pos + int(r["id_begin"]) + int(r["id_len"])].decode("utf-8")
-                       for r in recs]
+                begins = (recs["id_begin"] + pos).tolist()
+                ends = (recs["id_begin"] + recs["id_len"] + pos).tolist()
+                ids = [buf[b:e].decode("utf-8") for b, e in zip(begins, ends)]
                 n_fields = recs["n_fields"].copy()
                 for i in np.flatnonzero(recs["flag"] == FALLBACK):
                     line = buf[pos + int(recs["raw_begin"][i]):pos + int(recs["raw_end"][i])].decode("utf-8")
