@@ -7,7 +7,8 @@
  * reference root):
  *
  *   stag_encode_a2m*      <- stag/align.py:28-58   convert_alignment  (+ :160 min_perc_state filter)
- *   stag_backtranslate    <- stag/align.py:63-94   protein2gene_alignment
+ *   stag_backtranslate*   <- stag/align.py:63-94   protein2gene_alignment (host: one pair; _dev: a batch)
+ *   stag_classify_protein_a2m* <- stag/align.py:155-164 + stag/classify.py:155-158 for protein databases
  *   stag_classify_bits*   <- stag/classify.py:22-124  run_logistic_prediction, find_best_score,
  *                            predict_iter, find_correct_level, find_n_aligned_characters, classify_seq
  *   stag_classify_a2m*    <- the loop body of stag/classify.py:155-158 fed by stag/align.py:149-164
@@ -48,6 +49,8 @@ extern "C" {
 #define STAG_SEQ_ZERO_COLUMNS 5       /* ZeroDivisionError: n_char == 0              align.py:58 */
 #define STAG_SEQ_FILTERED 6           /* below min_perc_state: not yielded           align.py:160 */
 #define STAG_SEQ_LENGTH_MISMATCH 7    /* ValueError: 5*n_char != L (coeff * seq)     classify.py:25 */
+#define STAG_SEQ_BACKTRANSLATE 8      /* protein2gene_alignment returned None (align.py:66-74); the reference
+                                         then fails with TypeError in convert_alignment(None) */
 
 /*
  * Host-side description of one single-gene database (what load_db returns), already
@@ -129,7 +132,27 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
 int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
                           int64_t n, double min_perc_state, const stag_results_t *d_out, void *stream);
 
-/* align.py:63-94 on the host (string work; the GPU version is a later row of SURVEY.md 8f).
+/*
+ * align.py:63-94 on the GPU for n (protein alignment, gene) pairs laid out like the A2M text
+ * (record i = text[offs[i] .. offs[i+1])).  Record i's codon alignment is written to
+ * d_out[d_out_begin[i] .. d_out_end[i]) with d_out_begin[i] = 3 * prot_offs[i]; d_out must hold
+ * 3 * prot_bytes bytes.  d_status[i]: STAG_SEQ_OK, or STAG_SEQ_BACKTRANSLATE when check_length is
+ * set and the gene is neither 3x nor 3x+3 the number of non-'-' characters (then nothing is written).
+ */
+int stag_backtranslate_dev(const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs, const char *d_gene,
+                           const int64_t *d_gene_offs, int64_t n, int32_t check_length, char *d_out, int64_t out_bytes,
+                           int64_t *d_out_begin, int64_t *d_out_end, int32_t *d_status, void *stream);
+
+/* Protein databases (align.py:155-160 + :162 + classify.py:155-158): back-translate, encode and
+ * classify without the codon alignment leaving the GPU.  Arguments as stag_classify_a2m. */
+int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *prot_offs, const char *gene,
+                              const int64_t *gene_offs, int64_t n, double min_perc_state, const stag_results_t *out,
+                              uint32_t *bits_out, int32_t *n_char_out);
+int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
+                                  const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
+                                  const stag_results_t *d_out, void *stream);
+
+/* align.py:63-94 on the host, one pair.
  * out must hold 3*prot_len bytes.  *out_len = -1 reproduces the reference's `return None`. */
 int stag_backtranslate(const char *prot, int64_t prot_len, const char *gene, int64_t gene_len,
                        int32_t check_length, char *out, int64_t *out_len);

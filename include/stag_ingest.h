@@ -13,8 +13,9 @@
  * consumes whole records only and reports how many bytes it used.  The caller keeps the rest,
  * appends the next read and calls again; `final` != 0 says no more bytes will come.
  *
- * Exactness: anything the fast path cannot reproduce byte for byte (non-ASCII whitespace at a
- * line end, fields other than "0"/"1") is not guessed at: the record is flagged
+ * Exactness: anything the fast path cannot reproduce byte for byte (non-ASCII bytes in a FASTA
+ * line, a '\r' inside one -- a line break for a text-mode reader --, fields other than "0"/"1")
+ * is not guessed at: the record is flagged
  * STAG_INGEST_FALLBACK and the caller re-parses its raw bytes [raw_begin, raw_end) the slow way.
  */
 #ifndef STAG_INGEST_H

@@ -452,6 +452,20 @@ def gen_ingest():
         got = list(ref_helpers.read_fasta(io.BytesIO(data), head_start=1))
         fasta[name] = {"hex": data.hex(), "records": [[sid, seq] for sid, seq in got]}
 
+    # the gene file of align.py:150 is read in text mode: universal newlines
+    fasta_text = {}
+    text_cases = dict(fasta_cases)
+    text_cases["lone_cr"] = b">a\rAC\rGT\n>b\rTT\r"
+    text_cases["cr_before_header"] = b">a\nAC\r>b\nGG\n"
+    text_cases["cr_inside_header"] = b">a x\rAC\n>b\nGG\n"
+    for name, data in text_cases.items():
+        with tempfile.NamedTemporaryFile("wb", suffix=".fa", delete=False) as fh:
+            fh.write(data)
+        with open(fh.name) as tfh:
+            got = list(ref_helpers.read_fasta(tfh, is_binary=False, head_start=1))
+        os.remove(fh.name)
+        fasta_text[name] = {"hex": data.hex(), "records": [[sid, seq] for sid, seq in got]}
+
     onehot_cases = {
         "plain": "a\t0\t1\t1\t0\t0\nb\t1\t0\t0\t0\t0\n",
         "crlf_cr": "a\t0\t1\r\nb\t1\t0\rc\t1\t1\n",
@@ -478,7 +492,7 @@ def gen_ingest():
             rows, err = None, type(e).__name__
         os.remove(fh.name)
         onehot[name] = {"hex": text.encode("utf-8").hex(), "rows": rows, "raises": err}
-    dump("ingest.json", {"fasta": fasta, "onehot": onehot})
+    dump("ingest.json", {"fasta": fasta, "fasta_text": fasta_text, "onehot": onehot})
 
 
 if __name__ == "__main__":

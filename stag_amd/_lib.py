@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("STAG_HIP_LIB") or os.path.join(_HERE, "lib", "libstag
 
 STAG_OK = 0
 SEQ_OK, SEQ_MISSING_CLASSIFIER, SEQ_STRING_CLASSIFIER, SEQ_RANKCUT_SHAPE, SEQ_EMPTY_PATH, \
-    SEQ_ZERO_COLUMNS, SEQ_FILTERED, SEQ_LENGTH_MISMATCH = range(8)
+    SEQ_ZERO_COLUMNS, SEQ_FILTERED, SEQ_LENGTH_MISMATCH, SEQ_BACKTRANSLATE = range(9)
 PROF_CLASSES = ("encode", "walk_level", "group", "rankcut", "other")
 
 c_p = ctypes.c_void_p
@@ -55,6 +55,12 @@ EXPORTS = {
                                              ctypes.POINTER(Results), c_p]),
     "stag_backtranslate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
+    "stag_backtranslate_dev": (ctypes.c_int, [c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int64, ctypes.c_int32, c_p,
+                                              ctypes.c_int64, c_p, c_p, c_p, c_p]),
+    "stag_classify_protein_a2m": (ctypes.c_int, [c_p, c_p, c_p, c_p, c_p, ctypes.c_int64, ctypes.c_double,
+                                                 ctypes.POINTER(Results), c_p, c_p]),
+    "stag_classify_protein_a2m_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int64,
+                                                     ctypes.c_double, ctypes.POINTER(Results), c_p]),
     "stag_profile_enable": (ctypes.c_int, [c_p, ctypes.c_int32]),
     "stag_profile_read": (ctypes.c_int, [c_p, c_p, c_p]),
 }

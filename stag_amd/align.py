@@ -13,7 +13,6 @@ import sys
 
 from . import _lib, ingest
 from .helpers import is_tool, read_fasta
-from .tables import pack_text
 
 BATCH_RECORDS = 1 << 16      # records handed to the GPU at a time
 
@@ -92,18 +91,32 @@ def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
 
 
 def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose, size=None):
-    """Batches (ids, text uint8, offs int64) of aligned records for Database.classify_a2m_text.
-    Nucleotide databases go from the pipe to the batch in C (stag_amd.ingest.fasta_batches: no
-    Python string per record); protein databases pair every record with its gene and
-    back-translate it first (align.py:155-160)."""
+    """Batches (ids, text uint8, offs int64, gene) of aligned records, parsed in C
+    (stag_amd.ingest.fasta_batches: no Python string per record).  gene is None for nucleotide
+    databases (text/offs is the A2M alignment, for Database.classify_a2m_text); for protein
+    databases text/offs is the protein alignment and gene = (gene text, gene offs) of the same
+    records (align.py:148-158), for Database.classify_protein_a2m_text, which back-translates
+    on the GPU."""
     size = size or BATCH_RECORDS
-    if protein_file:
-        for ids, seqs in batched(aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose), size):
-            text, offs = pack_text(seqs)
-            yield ids, text, offs
-        return
     align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
-    yield from ingest.fasta_batches(parse_proc.stdout, batch_records=size)
+    if not protein_file:
+        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size):
+            yield ids, text, offs, None
+        _finish_aligner(align_proc, parse_proc)
+        return
+    with open(seq_file, "rb") as gene_fh:
+        genes = ingest.fasta_batches(gene_fh, batch_records=size, text_mode=True)
+        for pids, ptext, poffs in ingest.fasta_batches(parse_proc.stdout, batch_records=size):
+            gids, gtext, goffs = next(genes, ([], None, None))
+            m = min(len(pids), len(gids))          # zip() stops with the shorter stream (align.py:148)
+            for pid, gid in zip(pids[:m], gids[:m]):
+                if pid != gid:
+                    sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(pid, gid))
+                    sys.exit(1)
+            if m:
+                yield pids[:m], ptext, poffs[:m + 1], (gtext, goffs[:m + 1])
+            if m < len(pids):
+                break
     _finish_aligner(align_proc, parse_proc)
 
 

@@ -64,6 +64,19 @@ def _classify_prealigned(db, aligned_sequences, tagged, state):
         tagged.append((b, db.result_rows(res, ids, long_out=True)))
 
 
+def _report_backtranslation_failure(status, ids, text, offs, gene):
+    """The message protein2gene_alignment writes (align.py:70-73) before the reference fails on
+    that sequence -- only if it is the first failing sequence, as the reference stops there."""
+    bad = np.flatnonzero((status != _lib.SEQ_OK) & (status != _lib.SEQ_FILTERED))
+    if bad.size and status[bad[0]] == _lib.SEQ_BACKTRANSLATE:
+        i = int(bad[0])
+        prot = np.asarray(text[offs[i]:offs[i + 1]])
+        n_res = int((prot != ord("-")).sum())
+        sys.stderr.write("Error, length of genes/alignment is not correct")
+        sys.stderr.write(" (protein: " + str(n_res * 3) + ", gene: " + str(int(gene[1][i + 1] - gene[1][i])) + ")\n")
+        sys.stderr.write(" ID: " + ids[i] + "\n")
+
+
 def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, threads=1, output=None,
              long_out=False, current_tool_version=tool_version,
              aligned_sequences=None, save_ali_to_file=None, min_perc_state=0, internal_call=False, device=None):
@@ -90,12 +103,17 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                                             threads, verbose)
             alignment_out = open(save_ali_to_file, "wb") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
             with alignment_out:
-                for b, (ids, text, offs) in enumerate(batches):
+                for b, (ids, text, offs, gene) in enumerate(batches):
                     mine = parallel.owner_of_batch(b, world) == rank
                     if not mine and not (save_ali_to_file and rank == 0) and state["alignment_length"]:
                         continue
-                    res = db.classify_a2m_text(text, offs, min_perc_state=min_perc_state,
-                                               want_bits=bool(save_ali_to_file) and rank == 0)
+                    want_bits = bool(save_ali_to_file) and rank == 0
+                    if gene is None:
+                        res = db.classify_a2m_text(text, offs, min_perc_state=min_perc_state, want_bits=want_bits)
+                    else:       # protein database: back-translation happens on the GPU (align.py:63-94)
+                        res = db.classify_protein_a2m_text(text, offs, gene[0], gene[1], min_perc_state=min_perc_state,
+                                                           want_bits=want_bits)
+                    _report_backtranslation_failure(res.status, ids, text, offs, gene)
                     raise_for_status(res.status, ids)
                     passed = np.flatnonzero(res.status == _lib.SEQ_OK)
                     n_pass += len(passed)

@@ -85,8 +85,9 @@ struct stag_db {
     DevBuf<Task> tasks;
     DevBuf<uint32_t> bits, win;
     DevBuf<double> chunkgap;
-    DevBuf<uint8_t> text;
-    DevBuf<int64_t> offs;
+    DevBuf<uint8_t> text, gene_text, bt_text;
+    DevBuf<int64_t> offs, gene_offs, bt_begin, bt_end;
+    DevBuf<int32_t> bt_status;
     DevBuf<int32_t> enc_n_char, enc_status;
     // results (used when the caller passes NULL or host pointers)
     DevBuf<int32_t> r_path_node, r_path_len, r_lead, r_selected, r_n_aligned, r_status;
@@ -99,7 +100,8 @@ struct stag_db {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
         count.release(); lvl.release(); task_off.release(); n_tasks.release(); tasks.release();
-        bits.release(); win.release(); chunkgap.release(); text.release(); offs.release(); enc_n_char.release(); enc_status.release();
+        bits.release(); win.release(); chunkgap.release(); text.release(); offs.release();
+        gene_text.release(); bt_text.release(); gene_offs.release(); bt_begin.release(); bt_end.release(); bt_status.release(); enc_n_char.release(); enc_status.release();
         r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
         for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -148,7 +150,7 @@ int launch_check(const char *what) {
 
 int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
                double min_perc, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned, int32_t *d_status,
-               uint32_t *d_win, hipStream_t st) {
+               uint32_t *d_win, hipStream_t st, const int64_t *d_ends = nullptr, const int32_t *d_pre_status = nullptr) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
@@ -176,7 +178,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
             HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         Prof p(db_for_prof, st, 0);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
-                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win);
+                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win, d_ends, d_pre_status);
         return STAG_OK;
     };
     int rc = G == 64 ? launch(k_encode_a2m<64>) : G == 32 ? launch(k_encode_a2m<32>) : launch(k_encode_a2m<16>);
@@ -583,6 +585,74 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
     HIP_TRY(hipMemcpy(db->offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     if ((rc = stag_classify_a2m_dev(db, (const char *)db->text.p, (text_bytes + 15) / 16 * 16, db->offs.p, n, min_perc_state, nullptr,
                                     nullptr)))
+        return rc;
+    if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;
+    if (bits_out) HIP_TRY(hipMemcpy(bits_out, db->bits.p, (size_t)n * db->W * 4, hipMemcpyDeviceToHost));
+    if (n_char_out) HIP_TRY(hipMemcpy(n_char_out, db->enc_n_char.p, n * 4, hipMemcpyDeviceToHost));
+    return STAG_OK;
+}
+
+int stag_backtranslate_dev(const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs, const char *d_gene,
+                           const int64_t *d_gene_offs, int64_t n, int32_t check_length, char *d_out, int64_t out_bytes,
+                           int64_t *d_out_begin, int64_t *d_out_end, int32_t *d_status, void *stream) {
+    if (n < 0 || prot_bytes < 0 || (n > 0 && (!d_prot || !d_prot_offs || !d_gene || !d_gene_offs || !d_out || !d_out_begin ||
+                                               !d_out_end || !d_status)))
+        return fail(STAG_E_INVALID, "bad argument");
+    if (out_bytes < 3 * prot_bytes) return fail(STAG_E_INVALID, "d_out must hold 3 * prot_bytes = %lld bytes", (long long)(3 * prot_bytes));
+    if (n == 0) return STAG_OK;
+    if ((n + 3) / 4 > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    hipLaunchKernelGGL(k_backtranslate, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_prot, d_prot_offs, (const uint8_t *)d_gene, d_gene_offs, n, (int)check_length,
+                       (uint8_t *)d_out, d_out_begin, d_out_end, d_status);
+    return launch_check("k_backtranslate");
+}
+
+int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
+                                  const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
+                                  const stag_results_t *d_out, void *stream) {
+    if (!db || n < 0 || prot_bytes < 0 || (n > 0 && (!d_prot || !d_prot_offs || !d_gene || !d_gene_offs)))
+        return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    const int64_t bt_bytes = (3 * prot_bytes + 31) / 16 * 16;
+    int rc;
+    if ((rc = stag_db_reserve(db, n, bt_bytes)) || (rc = db->bt_text.reserve(bt_bytes)) || (rc = db->bt_begin.reserve(n)) ||
+        (rc = db->bt_end.reserve(n)) || (rc = db->bt_status.reserve(n)))
+        return rc;
+    hipStream_t st = (hipStream_t)stream;
+    {
+        Prof p(db, st, 4);
+        if ((rc = stag_backtranslate_dev(d_prot, prot_bytes, d_prot_offs, d_gene, d_gene_offs, n, 1, (char *)db->bt_text.p,
+                                         bt_bytes, db->bt_begin.p, db->bt_end.p, db->bt_status.p, stream)))
+            return rc;
+    }
+    const Out o = resolve(db, d_out);
+    if ((rc = encode_dev(db, db->L, (const char *)db->bt_text.p, bt_bytes, db->bt_begin.p, n, min_perc_state, db->bits.p,
+                         db->enc_n_char.p, o.n_aligned, db->enc_status.p, db->win.p, st, db->bt_end.p, db->bt_status.p)))
+        return rc;
+    return walk_dev(db, db->bits.p, n, db->enc_status.p, o, false, st);
+}
+
+int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *prot_offs, const char *gene,
+                              const int64_t *gene_offs, int64_t n, double min_perc_state, const stag_results_t *out,
+                              uint32_t *bits_out, int32_t *n_char_out) {
+    if (!db || n < 0 || !out || (n > 0 && (!prot || !prot_offs || !gene || !gene_offs || !out->status)))
+        return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    const int64_t pb = prot_offs[n], gb = gene_offs[n];
+    if (prot_offs[0] < 0 || pb < prot_offs[0] || gene_offs[0] < 0 || gb < gene_offs[0])
+        return fail(STAG_E_INVALID, "offs must be non-decreasing");
+    int rc;
+    if ((rc = db->text.reserve(pb + 16)) || (rc = db->offs.reserve(n + 1)) || (rc = db->gene_text.reserve(gb + 16)) ||
+        (rc = db->gene_offs.reserve(n + 1)))
+        return rc;
+    HIP_TRY(hipMemcpy(db->text.p, prot, pb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->offs.p, prot_offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->gene_text.p, gene, gb, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(db->gene_offs.p, gene_offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    if ((rc = stag_classify_protein_a2m_dev(db, (const char *)db->text.p, pb, db->offs.p, (const char *)db->gene_text.p,
+                                            db->gene_offs.p, n, min_perc_state, nullptr, nullptr)))
         return rc;
     if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;
     if (bits_out) HIP_TRY(hipMemcpy(bits_out, db->bits.p, (size_t)n * db->W * 4, hipMemcpyDeviceToHost));

@@ -34,7 +34,7 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
         const int64_t next = nl ? line_end + 1 : len;
         if (buf[pos] == '>') {
             if (open) {   /* the previous record ends where this header begins */
-                if (r_lines > 0) {
+                if (r_lines > 0 || fb) {   /* a flagged header may hide lines behind a '\r' */
                     recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = pos;
                     recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
                     offs[++n] = used;
@@ -47,6 +47,7 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
             }
             fb = 0;
             const int64_t e = rstrip_end(buf, pos, line_end, &fb);
+            if (memchr(buf + pos, '\r', (size_t)(e - pos))) fb = 1;   /* a line break for text-mode readers */
             open = 1;
             r_begin = pos; r_id = pos + 1; r_idlen = e - (pos + 1); r_lines = 0; r_text = used;
         } else {
@@ -60,21 +61,21 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
             for (int64_t i = pos; i < e; ++i) {
                 const unsigned char c = (unsigned char)buf[i];
                 text_out[used + (i - pos)] = (char)c;
-                hi |= c;
+                hi |= c | (unsigned char)(c == '\r' ? 0x80 : 0);
             }
-            if (hi & 0x80) fb = 1;
+            if (hi & 0x80) fb = 1;   /* also an inner '\r': a line break for text-mode readers */
             used += e - pos;
             ++r_lines;
         }
         pos = next;
     }
     if (final && pos >= len && open) {
-        if (r_lines > 0 && n < max_records) {
+        if ((r_lines > 0 || fb) && n < max_records) {
             recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = len;
             recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
             offs[++n] = used;
             *consumed = len;
-        } else if (r_lines == 0) {
+        } else if (r_lines == 0 && !fb) {
             used = r_text;
             *consumed = len;
         } else {

@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ n_char_out,
                                                     int32_t *__restrict__ n_aligned_out,
                                                     int32_t *__restrict__ status_out,
-                                                    uint32_t *__restrict__ win_out) {
+                                                    uint32_t *__restrict__ win_out,
+                                                    const int64_t *__restrict__ ends,
+                                                    const int32_t *__restrict__ pre_status) {
+    // ends (may be null): record i is text[offs[i] .. ends[i]) instead of [offs[i] .. offs[i+1]);
+    // pre_status (may be null): a non-zero entry is the record's final status (back-translation failed)
     extern __shared__ uint32_t s_enc[];  // one W-word row per record of the workgroup
     constexpr int RPW = 64 / G;          // records per wave
     const int lane = threadIdx.x & 63;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     uint32_t *row = s_enc + (size_t)(wave * RPW + grp) * W;
     for (int w = gl; w < W; w += G) row[w] = 0;
 
-    const int64_t begin = live ? offs[seq] : 0, end = live ? offs[seq + 1] : 0;
+    const int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
     // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
@@ -282,10 +286,62 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         if (running == 0) st = 5;
         else if (!((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
         else if ((int64_t)running * 5 != L) st = 7;
+        if (pre_status && pre_status[seq]) st = pre_status[seq];
         n_char_out[seq] = running;
         n_aligned_out[seq] = aligned;
         status_out[seq] = st;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// back-translation: stag/align.py:63-94 protein2gene_alignment.  One wave per (protein
+// alignment, gene) pair, 64 alignment characters per step.  '-' writes "---", an upper-case
+// residue the next three nucleotides of the gene, a lower-case residue (insert state) skips
+// three nucleotides, anything else does nothing.  Record i's output starts at 3 * prot_offs[i]
+// (an upper bound of what the records before it emit, so no scan over records is needed) and
+// ends at out_end[i].  status 8 = the length check of align.py:66-74 failed (the reference
+// returns None there and then fails in convert_alignment).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_backtranslate(const uint8_t *__restrict__ prot,
+                                                       const int64_t *__restrict__ prot_offs,
+                                                       const uint8_t *__restrict__ gene,
+                                                       const int64_t *__restrict__ gene_offs, int64_t n,
+                                                       int check_length, uint8_t *__restrict__ out,
+                                                       int64_t *__restrict__ out_begin, int64_t *__restrict__ out_end,
+                                                       int32_t *__restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int64_t rec = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (rec >= n) return;
+    const int64_t p0 = prot_offs[rec], p1 = prot_offs[rec + 1];
+    const int64_t g0 = gene_offs[rec], glen = gene_offs[rec + 1] - g0;
+    const int64_t o0 = 3 * p0;
+    if (check_length) {
+        int64_t residues = 0;   // every character that is not '-' (align.py:65)
+        for (int64_t p = p0 + lane; p < p1; p += 64) residues += prot[p] != '-';
+        residues = wave_sum((int)residues);
+        if (glen != 3 * residues && glen - 3 != 3 * residues) {
+            if (lane == 0) { out_begin[rec] = o0; out_end[rec] = o0; status[rec] = 8; }
+            return;
+        }
+    }
+    int64_t consumed = 0, emitted = 0;   // residues that took a codon / characters written, before this step
+    for (int64_t base = p0; base < p1; base += 64) {
+        const int64_t p = base + lane;
+        const uint8_t c = p < p1 ? prot[p] : (uint8_t)'.';
+        const bool dash = c == '-', upper = c >= 'A' && c <= 'Z', lower = c >= 'a' && c <= 'z';
+        const int takes = (upper || lower) ? 1 : 0;
+        const int t_incl = wave_incl_scan(takes, lane);
+        const int64_t g = 3 * (consumed + t_incl - takes);           // this residue's codon in the gene
+        int e = 0;
+        if (dash) e = 3;
+        else if (upper) e = (int)min((int64_t)3, max((int64_t)0, glen - g));   // a slice past the end is shorter
+        const int e_incl = wave_incl_scan(e, lane);
+        uint8_t *dst = out + o0 + emitted + (e_incl - e);
+        for (int j = 0; j < e; ++j) dst[j] = dash ? (uint8_t)'-' : gene[g0 + g + j];
+        consumed += __shfl(t_incl, 63);
+        emitted += __shfl(e_incl, 63);
+    }
+    if (lane == 0) { out_begin[rec] = o0; out_end[rec] = o0 + emitted; status[rec] = 0; }
 }
 
 // find_n_aligned_characters (classify.py:79-87) and the R0 window for rows that did not come

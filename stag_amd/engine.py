@@ -18,6 +18,8 @@ _EXC = {
     _lib.SEQ_RANKCUT_SHAPE: (ValueError, "operands could not be broadcast together in the rank cut (stag/classify.py:25)"),
     _lib.SEQ_EMPTY_PATH: (IndexError, "list index out of range: empty path (stag/classify.py:106)"),
     _lib.SEQ_ZERO_COLUMNS: (ZeroDivisionError, "division by zero: no alignment column (stag/align.py:58)"),
+    _lib.SEQ_BACKTRANSLATE: (TypeError, "'NoneType' object is not iterable: gene and protein alignment lengths do not "
+                                        "fit (stag/align.py:66-74, then :37)"),
     _lib.SEQ_LENGTH_MISMATCH: (ValueError, "operands could not be broadcast together: alignment length differs "
                                           "from the database's (stag/classify.py:25)"),
 }
@@ -163,6 +165,31 @@ class Database:
             res.bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
         _lib.check(_lib.lib().stag_classify_a2m(self.handle, _lib.ptr(text), _lib.ptr(offs), n, float(min_perc_state),
                                                 ctypes.byref(st), _lib.ptr(res.bits), _lib.ptr(res.n_char)))
+        res.level_prob = res.level_prob[:, :self.n_keys]
+        return res
+
+    def classify_protein_a2m_text(self, prot_text, prot_offs, gene_text, gene_offs, min_perc_state=0.0, want_bits=False):
+        """Protein database: (protein alignment, gene) pairs -> back-translate (align.py:63-94),
+        encode and classify on the GPU.  Record i = text[offs[i]:offs[i+1]] in both pairs of arrays."""
+        pt = np.ascontiguousarray(prot_text, dtype=np.uint8)
+        po = np.ascontiguousarray(prot_offs, dtype=np.int64)
+        gt = np.ascontiguousarray(gene_text, dtype=np.uint8)
+        go = np.ascontiguousarray(gene_offs, dtype=np.int64)
+        n = len(po) - 1
+        if n < 0 or len(go) != n + 1 or (n > 0 and (po[-1] > len(pt) or go[-1] > len(gt))):
+            raise ValueError("offsets do not describe n records inside their texts")
+        if len(pt) == 0:
+            pt = np.zeros(16, dtype=np.uint8)
+        if len(gt) == 0:
+            gt = np.zeros(16, dtype=np.uint8)
+        res = BatchResult(n, self.max_depth, self.n_keys)
+        st = res.as_struct()
+        res.n_char = np.zeros(n, dtype=np.int32)
+        if want_bits:
+            res.bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
+        _lib.check(_lib.lib().stag_classify_protein_a2m(self.handle, _lib.ptr(pt), _lib.ptr(po), _lib.ptr(gt), _lib.ptr(go),
+                                                        n, float(min_perc_state), ctypes.byref(st), _lib.ptr(res.bits),
+                                                        _lib.ptr(res.n_char)))
         res.level_prob = res.level_prob[:, :self.n_keys]
         return res
 

@@ -78,10 +78,12 @@ def _fill(stream, buf, have):
     return have, False
 
 
-def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1):
+def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False):
     """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
-    (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1)."""
+    (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1); with
+    text_mode, as read_fasta(open(path), is_binary=False): universal newlines, so a lone '\r' also
+    ends a line (the gene file of align.py:150)."""
     L = lib()
     buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
     scratch = np.empty(len(buf), dtype=np.uint8)
@@ -119,7 +121,11 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
             if n and (recs["flag"] == FALLBACK).any():
                 # non-ASCII bytes in a line: let Python's str methods decide, as the reference does
                 raw = bytes(view[int(recs["raw_begin"][0]):int(recs["raw_end"][-1])])
-                pairs = list(read_fasta(io.BytesIO(raw), head_start=head_start))
+                if text_mode:
+                    pairs = list(read_fasta(io.TextIOWrapper(io.BytesIO(raw), encoding="utf-8", newline=None),
+                                            head_start=head_start, is_binary=False))
+                else:
+                    pairs = list(read_fasta(io.BytesIO(raw), head_start=head_start))
                 t, o = pack_text([s for _, s in pairs])
                 ids.extend(sid for sid, _ in pairs)
                 texts.append(t[:int(o[-1])].copy())

@@ -44,6 +44,14 @@ class OracleDatabase(Database):
         strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(len(offs) - 1)]
         return self.classify_a2m(strings, min_perc_state, want_bits)
 
+    def classify_protein_a2m_text(self, ptext, poffs, gtext, goffs, min_perc_state=0.0, want_bits=False):
+        n = len(poffs) - 1
+        cut = lambda t, o, i: bytes(t[o[i]:o[i + 1]]).decode("latin-1")
+        nuc = [oracle_c.protein2gene(cut(ptext, poffs, i), cut(gtext, goffs, i), True) for i in range(n)]
+        res = self.classify_a2m([s or "" for s in nuc], min_perc_state, want_bits)
+        res.status[[s is None for s in nuc]] = _lib.SEQ_BACKTRANSLATE
+        return res
+
     def classify_a2m(self, strings, min_perc_state=0.0, want_bits=False):
         from stag_amd.tables import pack_bool_rows
         n = len(strings)

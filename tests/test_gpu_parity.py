@@ -318,3 +318,92 @@ def test_empty_batch_and_bad_arguments():
     bad.child_first = np.array([1, 3, 2, 3], dtype=np.int32)   # not monotone
     with pytest.raises(_lib.StagError):
         Database(bad)
+
+
+# ------------------------------------------------------------------ protein databases (align.py:63-94)
+def backtranslate_gpu(pairs, check_length=True):
+    """stag_backtranslate_dev on device buffers (tests/hipmem.py supplies the memory)."""
+    from hipmem import DevArray
+    pt, po = tables.pack_text([p for p, _ in pairs])
+    gt, go = tables.pack_text([g for _, g in pairs])
+    n = len(pairs)
+    d_pt, d_po, d_gt, d_go = DevArray(pt), DevArray(po), DevArray(gt), DevArray(go)
+    cap = 3 * int(po[-1]) + 16
+    out, ob, oe = DevArray(shape=(cap,), dtype=np.uint8), DevArray(shape=(n,), dtype=np.int64), DevArray(shape=(n,), dtype=np.int64)
+    st = DevArray(shape=(n,), dtype=np.int32)
+    _lib.check(_lib.lib().stag_backtranslate_dev(d_pt.ptr, int(po[-1]), d_po.ptr, d_gt.ptr, d_go.ptr, n, int(check_length),
+                                                 out.ptr, cap, ob.ptr, oe.ptr, st.ptr, None))
+    out, ob, oe, st = out.get(), ob.get(), oe.get(), st.get()
+    assert np.array_equal(ob, 3 * po[:-1])
+    return [None if st[i] else bytes(out[ob[i]:oe[i]]).decode("latin-1") for i in range(n)], st
+
+
+def host_backtranslate(prot, gene, check_length=True):
+    from stag_amd.align import protein2gene_alignment
+    return protein2gene_alignment("x", prot, gene, check_length)
+
+
+def test_backtranslate_dev_golden_and_random(capfd):
+    g = gu.load("backtranslate.json")
+    for check in (True, False):
+        cases = [c for c in g if c["check_length"] == check]
+        got, st = backtranslate_gpu([(c["protein"], c["gene"]) for c in cases], check)
+        for c, r, s in zip(cases, got, st):
+            assert r == c["result"], c
+            assert s == (_lib.SEQ_BACKTRANSLATE if c["result"] is None else 0)
+    rng = np.random.default_rng(123)
+    pairs = []
+    for i in range(600):
+        m = int(rng.integers(0, 400))
+        prot = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY-acdefgh.*"), size=m,
+                                  p=[0.03] * 20 + [0.2] + [0.02] * 7 + [0.03, 0.03]))
+        res = sum(ch != "-" for ch in prot)
+        glen = 3 * res + (3 if i % 3 == 0 else 0) + (int(rng.integers(-4, 5)) if i % 7 == 0 else 0)
+        pairs.append((prot, "".join(rng.choice(list("ACGT"), size=max(glen, 0)))))
+    for check in (True, False):
+        got, _ = backtranslate_gpu(pairs, check)
+        for (p, gseq), r in zip(pairs, got):
+            assert r == host_backtranslate(p, gseq, check)
+    capfd.readouterr()
+
+
+def test_classify_protein_a2m_equals_host_backtranslation(capfd):
+    """Protein path fused on the GPU == host back-translation (pinned to the reference) followed by
+    the nucleotide path: same kernels downstream, so everything is bit-identical."""
+    rng = np.random.default_rng(321)
+    naa = 40
+    ncol = 3 * naa
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[3], [2, 2, 3]], 0.1)
+    prots, genes = [], []
+    for i in range(300):
+        cols = rng.choice(list("ACDEFGHIKL-"), size=naa, p=[0.08] * 10 + [0.2])
+        s = list(cols)
+        for _ in range(int(rng.integers(0, 3))):
+            s.insert(int(rng.integers(0, len(s) + 1)), rng.choice(list("acd")))
+        prot = "".join(s)
+        res = sum(ch != "-" for ch in prot)
+        glen = 3 * res + (3 if i % 2 else 0)
+        if i % 23 == 0:
+            glen += 1                                   # length check fails: the reference returns None
+        prots.append(prot)
+        genes.append("".join(rng.choice(list("ACGTN"), size=glen, p=[0.24, 0.24, 0.24, 0.24, 0.04])))
+    pt, po = tables.pack_text(prots)
+    gt, go = tables.pack_text(genes)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        res = db.classify_protein_a2m_text(pt, po, gt, go, min_perc_state=30.0, want_bits=True)
+        nuc = [host_backtranslate(p, gseq) for p, gseq in zip(prots, genes)]
+        bad = np.array([s is None for s in nuc])
+        assert bad.sum() >= 10 and np.array_equal(res.status == _lib.SEQ_BACKTRANSLATE, bad)
+        ref = db.classify_a2m([s or "" for s in nuc], min_perc_state=30.0, want_bits=True)
+        ok = ~bad
+        assert (res.status[ok] == 0).sum() > 100
+        for f in ("status", "n_char", "n_aligned", "path_len", "selected", "n_lead_single"):
+            assert np.array_equal(getattr(res, f)[ok], getattr(ref, f)[ok]), f
+        assert np.array_equal(res.bits[ok], ref.bits[ok])
+        assert np.array_equal(res.path_node[ok], ref.path_node[ok])
+        assert np.array_equal(res.path_prob[ok], ref.path_prob[ok])
+        assert np.array_equal(res.level_prob[ok], ref.level_prob[ok])
+        with pytest.raises(TypeError):
+            raise_for_status(res.status)
+    capfd.readouterr()

@@ -118,6 +118,60 @@ def test_classify_from_aligner_pipe_with_fake_tools(fake_gpu, monkeypatch, tmp_p
         sc.classify("db", fasta_input=str(fasta), output=str(tmp_path / "o2"), verbose=1)
 
 
+def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_path, capsys):
+    """protein_fasta_input path: the protein alignment from the pipe is paired with the gene file
+    (text mode, CRLF here), back-translated and classified; rows equal the nucleotide path's."""
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)       # L = 80: 16 columns -> needs a multiple of 3
+    taxonomy, tax_function, classifiers = gu.db_from_json(g["db"])
+    rng = np.random.default_rng(4)
+    L = 5 * 18
+    classifiers = {k: (v if isinstance(v, str) else rng.normal(0, 1, size=1 + L)) for k, v in classifiers.items()}
+
+    def fake_load_db(path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):
+        hmm = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        hmm.close()
+        return hmm.name, False, taxonomy, tax_function, classifiers, "0.8.2"
+
+    monkeypatch.setattr(sc, "load_db", fake_load_db)
+    prots, genes, nucs = [], [], []
+    for i in range(9):
+        prot = "".join(rng.choice(list("MKV-"), size=6))
+        prot = prot[:2] + "g" * (i % 2) + prot[2:]
+        res = sum(c != "-" for c in prot)
+        gene = "".join(rng.choice(list("ACGT"), size=3 * res + 3 * (i % 2)))
+        prots.append(prot)
+        genes.append(gene)
+        nucs.append(oracle_np.protein2gene_alignment("r%d" % i, prot, gene))
+    (tmp_path / "p.a2m").write_text("".join(">r%d\n%s\n" % (i, p) for i, p in enumerate(prots)))
+    gene_file = tmp_path / "genes.fna"
+    gene_file.write_bytes("".join(">r%d\r\n%s\r\n" % (i, s) for i, s in enumerate(genes)).encode())
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s\n" % (tmp_path / "p.a2m"))
+    (bindir / "esl-reformat").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat\n")
+    for t in ("hmmalign", "esl-reformat"):
+        os.chmod(bindir / t, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    prot_file = tmp_path / "prot.faa"
+    prot_file.write_text(">unused\nMKV\n")
+    n, rows = sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1,
+                          output=str(tmp_path / "o"), long_out=True)
+    assert n == L and len(rows) == 9
+    for i, row in enumerate(rows):
+        x, _ = oracle_np.convert_alignment(nucs[i])
+        gu.rows_match(row, oracle_np.classify_seq("r%d" % i, x, taxonomy, tax_function, classifiers), rtol=1e-12)
+    # a gene of the wrong length: message of align.py:70-73, then the reference's TypeError
+    gene_file.write_text("".join(">r%d\n%s\n" % (i, s + ("A" if i == 4 else "")) for i, s in enumerate(genes)))
+    capsys.readouterr()
+    with pytest.raises(TypeError):
+        sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o2"))
+    assert "length of genes/alignment is not correct" in capsys.readouterr().err
+    # identifiers that do not pair up: sys.exit(1) (align.py:152-154)
+    gene_file.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(genes)))
+    with pytest.raises(SystemExit):
+        sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o3"))
+
+
 def test_parse_onehot_line_matches_reference_reader():
     for line in ("id1\t0\t1\t0\t0\t1\n", "id2\t0\t10\t0\t-3\t1\n", "id3\t1\n", "x y\t0\t0\n"):
         gid, x = sc.parse_onehot_line(line)

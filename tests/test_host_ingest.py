@@ -49,6 +49,16 @@ def test_fasta_scan_matches_reference(name, chunk):
     assert got == case["records"]
 
 
+@pytest.mark.parametrize("name", sorted(G["fasta_text"]))
+@pytest.mark.parametrize("chunk", [1, 3, 64, 1 << 20])
+def test_fasta_scan_text_mode_matches_reference(name, chunk):
+    """The gene file of a protein database is read in text mode (align.py:150): '\r' ends a line."""
+    case = G["fasta_text"][name]
+    data = bytes.fromhex(case["hex"])
+    got = records_of(ingest.fasta_batches(io.BytesIO(data), chunk_bytes=chunk, text_mode=True))
+    assert got == case["records"]
+
+
 @pytest.mark.parametrize("batch", [1, 2, 5, 299, 300, 301])
 def test_fasta_scan_batch_limits(batch):
     case = G["fasta"]["many_wrapped"]
