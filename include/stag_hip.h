@@ -12,6 +12,7 @@
  *   stag_classify_bits*   <- stag/classify.py:22-124  run_logistic_prediction, find_best_score,
  *                            predict_iter, find_correct_level, find_n_aligned_characters, classify_seq
  *   stag_classify_a2m*    <- the loop body of stag/classify.py:155-158 fed by stag/align.py:149-164
+ *   stag_classify_concat  <- stag/classify_genome.py:364-388 concat_alignments + the classify call of :494
  *   stag_db_create        <- the in-memory result of stag/databases.py:36-108 load_db, packed
  *
  * Conventions: plain C types only; every function returns STAG_OK (0) or a negative
@@ -151,6 +152,19 @@ int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *pr
 int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
                                   const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
                                   const stag_results_t *d_out, void *stream);
+
+/*
+ * classify_genome.py:364-388 + :494 fused: the concatenated row of each genome is assembled on the
+ * GPU from the marker genes' packed rows and classified against the concatenated database, without
+ * the round trip through a text file of n_features 0/1 fields per genome.  Gene p (in the
+ * database's gene order) has gene_len[p] features and n_rows[p] packed rows of words_per_row[p]
+ * words at rows[p] (host); src_row[j * n_genes + p] is the row of gene p that belongs to genome j,
+ * or -1 when the genome lacks the gene (zero-filled, :375).  The gene lengths must add up to the
+ * database's n_features.  bits_out (may be NULL) receives the concatenated rows.
+ */
+int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len, const uint32_t *const *rows,
+                         const int32_t *words_per_row, const int64_t *n_rows, const int32_t *src_row, int64_t n_genomes,
+                         const stag_results_t *out, uint32_t *bits_out);
 
 /* align.py:63-94 on the host, one pair.
  * out must hold 3*prot_len bytes.  *out_len = -1 reproduces the reference's `return None`. */

@@ -61,6 +61,8 @@ EXPORTS = {
                                                  ctypes.POINTER(Results), c_p, c_p]),
     "stag_classify_protein_a2m_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int64,
                                                      ctypes.c_double, ctypes.POINTER(Results), c_p]),
+    "stag_classify_concat": (ctypes.c_int, [c_p, ctypes.c_int32, c_p, c_p, c_p, c_p, c_p, ctypes.c_int64,
+                                            ctypes.POINTER(Results), c_p]),
     "stag_profile_enable": (ctypes.c_int, [c_p, ctypes.c_int32]),
     "stag_profile_read": (ctypes.c_int, [c_p, c_p, c_p]),
 }

@@ -79,7 +79,12 @@ def _report_backtranslation_failure(status, ids, text, offs, gene):
 
 def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, threads=1, output=None,
              long_out=False, current_tool_version=tool_version,
-             aligned_sequences=None, save_ali_to_file=None, min_perc_state=0, internal_call=False, device=None):
+             aligned_sequences=None, save_ali_to_file=None, min_perc_state=0, internal_call=False, device=None,
+             packed_rows_out=None, concat_source=None):
+    """The reference's arguments, plus three of this build's own: `device` (GPU index),
+    `packed_rows_out` (a list that receives (ids, packed rows) of every batch written to
+    save_ali_to_file) and `concat_source` (marker-gene rows to concatenate on the GPU instead of
+    reading aligned_sequences; see classify_genome.concat_on_device)."""
     t0 = time.time()
     loaded = load_db(database, protein_fasta_input=protein_fasta_input, aligned_sequences=aligned_sequences)
     hmm_file_path, use_cmalign, taxonomy, tax_function, classifiers, db_tool_version = loaded
@@ -96,7 +101,12 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
     n_pass = n_not_pass = 0
     error = None
     try:
-        if aligned_sequences:
+        if concat_source is not None:      # classify_genome.py:364-388 + :494 without the text file
+            state["alignment_length"] = int(sum(concat_source["gene_len"]))
+            if rank == 0 and len(concat_source["ids"]):
+                res = db.classify_concat(concat_source["gene_len"], concat_source["gene_rows"], concat_source["src_row"])
+                tagged.append((0, db.result_rows(res, concat_source["ids"], long_out=True)))
+        elif aligned_sequences:
             _classify_prealigned(db, aligned_sequences, tagged, state)
         else:
             batches = align.aligned_batches(fasta_input, protein_fasta_input, hmm_file_path, use_cmalign,
@@ -125,6 +135,8 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                     if save_ali_to_file and rank == 0 and len(passed):      # classify.py:160-162
                         alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed],
                                                                  db.n_features))
+                        if packed_rows_out is not None:
+                            packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
             if verbose > 3 and world == 1:
                 print(f" Number of sequences that pass the filter: {n_pass}", file=sys.stderr)
                 print(f" Number of sequences that do not pass the filter: {n_not_pass}", file=sys.stderr)

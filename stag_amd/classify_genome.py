@@ -24,8 +24,10 @@ from .classify import classify
 from .databases import load_genome_DB
 
 
-def annotate_MGs(MGS, database_files, database_base_path, dir_ali, procs=2):
-    """classify_genome.py:307-341 without the fork pool: {sequence id: lineage}."""
+def annotate_MGs(MGS, database_files, database_base_path, dir_ali, procs=2, packed=None):
+    """classify_genome.py:307-341 without the fork pool: {sequence id: lineage}.  `packed` (a dict)
+    receives per marker gene (alignment length, [(ids, packed rows), ...]) of what was written
+    to dir_ali, for concat_on_device."""
     found_marker_genes = {
         mg: (fna, faa)
         for mg, (fna, faa) in MGS.items()
@@ -41,9 +43,12 @@ def annotate_MGs(MGS, database_files, database_base_path, dir_ali, procs=2):
     for mg, (fna, faa) in found_marker_genes.items():
         # "no_protein" marks a gene database aligned at the nucleotide level (:449-450)
         faa = None if faa in (None, "", "no_protein") else faa
-        _, predictions = classify(os.path.join(database_base_path, mg), fasta_input=fna, protein_fasta_input=faa,
+        batches = []
+        n, predictions = classify(os.path.join(database_base_path, mg), fasta_input=fna, protein_fasta_input=faa,
                                   save_ali_to_file=os.path.join(dir_ali, mg), internal_call=True, verbose=1,
-                                  threads=procs)
+                                  threads=procs, packed_rows_out=batches)
+        if packed is not None:
+            packed[mg] = (n, batches)
         d.update(predictions)
     return d
 
@@ -92,6 +97,37 @@ def concat_alignments(genome_files, ali_dir, gene_order, ali_lengths, full_genom
     return concat_ali_f.name
 
 
+def concat_on_device(packed, gene_order, ali_lengths):
+    """What concat_alignments (classify_genome.py:364-388) builds, as an index instead of text: the
+    genomes in order of first appearance (genes in gene_order, sequences in file order) and, per
+    genome and gene, which packed row is its alignment (the last one wins, as the dict assignment
+    of :378 does; -1 = the gene is missing and is zero-filled).  Returns None when a gene's rows do
+    not have the length the database announces (the text path then reproduces the reference's
+    failure)."""
+    import numpy as np
+    genomes, src = {}, []
+    gene_rows, gene_len = [], []
+    for pos, mg in enumerate(gene_order):
+        length = int(ali_lengths[mg])
+        gene_len.append(length)
+        n, batches = packed.get(mg, (None, []))
+        if batches and n != length:
+            return None
+        rows = [b for _, b in batches]
+        gene_rows.append(np.concatenate(rows) if rows else np.zeros((0, 4), dtype=np.uint32))
+        r = 0
+        for ids, _ in batches:
+            for seq_id in ids:
+                genome = _genome_of(seq_id)
+                j = genomes.setdefault(genome, len(genomes))
+                if j == len(src):
+                    src.append([-1] * len(gene_order))
+                src[j][pos] = r
+                r += 1
+    return {"ids": list(genomes), "gene_len": gene_len, "gene_rows": gene_rows,
+            "src_row": np.array(src, dtype=np.int32).reshape(len(src), len(gene_order))}
+
+
 def store_marker_sequences(marker_sequences, outdir, genome_files_available=True):
     """classify_genome.py:391-410."""
     def store_seqs(source, target, copy_function):
@@ -138,15 +174,23 @@ def classify_genome(database, genome_files=None, marker_genes=None, verbose=None
             sys.stderr.write("Taxonomically annotate single marker genes\n")
         align_dir = os.path.join(output, "MG_ali")
         pathlib.Path(align_dir).mkdir(exist_ok=True, parents=True)
-        all_classifications = annotate_MGs(MGS, database_files, temp_dir, align_dir, procs=threads)
+        packed = {}
+        all_classifications = annotate_MGs(MGS, database_files, temp_dir, align_dir, procs=threads, packed=packed)
         input_files = genome_files if genome_files else marker_genes
         merge_gene_predictions(input_files, list(database_files), all_classifications, verbose, threads, output,
                                long_out, keep_all_genes, full_genomes=bool(genome_files))
         if verbose > 2:
             sys.stderr.write("Taxonomically annotate genomes\n")
-        file_ali = concat_alignments(input_files, align_dir, gene_order, ali_lengths, full_genomes=bool(genome_files))
-        classify(concat_ali_stag_db, aligned_sequences=file_ali, output=os.path.join(output, "genome_annotation"),
-                 long_out=long_out, verbose=verbose)
-        os.remove(file_ali)
+        # the concatenated rows are assembled on the GPU from the rows the per-gene pass produced;
+        # the text round trip of the reference (:364-388, 2 bytes per feature and genome) is the fallback
+        source = concat_on_device(packed, gene_order, ali_lengths)
+        if source is not None:
+            classify(concat_ali_stag_db, aligned_sequences="<marker gene rows>", concat_source=source,
+                     output=os.path.join(output, "genome_annotation"), long_out=long_out, verbose=verbose)
+        else:
+            file_ali = concat_alignments(input_files, align_dir, gene_order, ali_lengths, full_genomes=bool(genome_files))
+            classify(concat_ali_stag_db, aligned_sequences=file_ali, output=os.path.join(output, "genome_annotation"),
+                     long_out=long_out, verbose=verbose)
+            os.remove(file_ali)
     finally:
         shutil.rmtree(temp_dir, ignore_errors=True)

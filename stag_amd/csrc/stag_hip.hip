@@ -592,6 +592,57 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
     return STAG_OK;
 }
 
+int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len, const uint32_t *const *rows,
+                         const int32_t *words_per_row, const int64_t *n_rows, const int32_t *src_row, int64_t n_genomes,
+                         const stag_results_t *out, uint32_t *bits_out) {
+    if (!db || n_genes < 1 || n_genomes < 0 || !gene_len || !rows || !words_per_row || !n_rows || !out ||
+        (n_genomes > 0 && (!src_row || !out->status)))
+        return fail(STAG_E_INVALID, "bad argument");
+    std::vector<int64_t> goff(n_genes + 1, 0), base(n_genes, 0);
+    int64_t arena_words = 0;
+    for (int p = 0; p < n_genes; ++p) {
+        if (gene_len[p] < 0 || n_rows[p] < 0 || words_per_row[p] < 1 || (int64_t)words_per_row[p] * 32 < gene_len[p] ||
+            (n_rows[p] > 0 && !rows[p]))
+            return fail(STAG_E_INVALID, "gene %d: bad length / row shape", p);
+        goff[p + 1] = goff[p] + gene_len[p];
+        base[p] = arena_words;
+        arena_words += n_rows[p] * words_per_row[p];
+    }
+    if (goff[n_genes] != db->L)
+        return fail(STAG_E_INVALID, "gene lengths add up to %lld features, the database has %d", (long long)goff[n_genes], db->L);
+    for (int64_t i = 0; i < n_genomes * n_genes; ++i)
+        if (src_row[i] >= n_rows[i % n_genes]) return fail(STAG_E_INVALID, "src_row[%lld] out of range", (long long)i);
+    if (n_genomes == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    int rc;
+    if ((rc = reserve_walk(db, n_genomes)) || (rc = db->bits.reserve((size_t)n_genomes * db->W))) return rc;
+    DevBuf<uint32_t> arena;
+    DevBuf<int64_t> d_tab;      // goff [n_genes+1], base [n_genes]
+    DevBuf<int32_t> d_itab;     // words_per_row [n_genes], src_row [n_genomes * n_genes]
+    auto done = [&](int code) { arena.release(); d_tab.release(); d_itab.release(); return code; };
+    if ((rc = arena.reserve(arena_words + 1)) || (rc = d_tab.reserve(2 * n_genes + 1)) ||
+        (rc = d_itab.reserve(n_genes + n_genomes * n_genes)))
+        return done(rc);
+    bool ok = true;
+    for (int p = 0; p < n_genes && ok; ++p)
+        if (n_rows[p])
+            ok = hipMemcpy(arena.p + base[p], rows[p], (size_t)n_rows[p] * words_per_row[p] * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemcpy(d_tab.p, goff.data(), (n_genes + 1) * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_tab.p + n_genes + 1, base.data(), n_genes * 8, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_itab.p, words_per_row, n_genes * 4, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(d_itab.p + n_genes, src_row, (size_t)n_genomes * n_genes * 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) return done(fail(STAG_E_HIP, "host to device copy failed"));
+    if (n_genomes > 65535) return done(fail(STAG_E_INVALID, "more than 65535 genomes in one call: split the batch"));
+    hipLaunchKernelGGL(k_concat_bits, dim3((unsigned)((db->W + 255) / 256), (unsigned)n_genomes), dim3(256), 0, nullptr, n_genomes,
+                       n_genes, d_tab.p, d_tab.p + n_genes + 1, d_itab.p, d_itab.p + n_genes, arena.p, db->bits.p, db->W);
+    if ((rc = launch_check("k_concat_bits"))) return done(rc);
+    if ((rc = walk_dev(db, db->bits.p, n_genomes, nullptr, resolve(db, nullptr), true, nullptr))) return done(rc);
+    if ((rc = copy_results_to_host(db, out, n_genomes, nullptr))) return done(rc);
+    if (bits_out && hipMemcpy(bits_out, db->bits.p, (size_t)n_genomes * db->W * 4, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(STAG_E_HIP, "device to host copy failed"));
+    return done(STAG_OK);
+}
+
 int stag_backtranslate_dev(const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs, const char *d_gene,
                            const int64_t *d_gene_offs, int64_t n, int32_t check_length, char *d_out, int64_t out_bytes,
                            int64_t *d_out_begin, int64_t *d_out_end, int32_t *d_status, void *stream) {

@@ -376,6 +376,45 @@ __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restric
 }
 
 // ------------------------------------------------------------------------------------------
+// concatenation of marker-gene rows: stag/classify_genome.py:364-388 on packed rows.  Output row
+// j (one genome) is the genes' rows laid end to end at bit offsets goff[p]; a gene the genome
+// lacks (src_row < 0) contributes zeros.  One thread per output word.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_concat_bits(int64_t n_genomes, int n_genes, const int64_t *__restrict__ goff,
+                                                     const int64_t *__restrict__ src_base,
+                                                     const int32_t *__restrict__ src_wpr,
+                                                     const int32_t *__restrict__ src_row,
+                                                     const uint32_t *__restrict__ arena, uint32_t *__restrict__ out,
+                                                     int W_out) {
+    const int w = blockIdx.x * 256 + threadIdx.x;
+    const int64_t j = blockIdx.y;
+    if (w >= W_out || j >= n_genomes) return;
+    const int64_t lo = 32ll * w, hi = lo + 32;
+    int a = 0, b = n_genes;   // first gene whose bits end after lo
+    while (a < b) {
+        const int m = (a + b) >> 1;
+        if (goff[m + 1] > lo) b = m; else a = m + 1;
+    }
+    uint32_t v = 0;
+    for (int p = a; p < n_genes && goff[p] < hi; ++p) {
+        const int r = src_row[j * n_genes + p];
+        if (r < 0) continue;
+        const int64_t d0 = max(lo, goff[p]), d1 = min(hi, goff[p + 1]);
+        const int nb = (int)(d1 - d0);
+        if (nb <= 0) continue;
+        const int64_t s0 = d0 - goff[p];
+        const int wpr = src_wpr[p];
+        const uint32_t *row = arena + src_base[p] + (int64_t)r * wpr;
+        const int i = (int)(s0 >> 5), sh = (int)(s0 & 31);
+        uint32_t x = row[i] >> sh;
+        if (sh && i + 1 < wpr) x |= row[i + 1] << (32 - sh);
+        if (nb < 32) x &= (1u << nb) - 1u;
+        v |= x << (int)(d0 - lo);
+    }
+    out[j * W_out + w] = v;
+}
+
+// ------------------------------------------------------------------------------------------
 // grouping by current node
 // ------------------------------------------------------------------------------------------
 // Only for a tree without levels (a root with no children): status is otherwise set by the

@@ -193,6 +193,29 @@ class Database:
         res.level_prob = res.level_prob[:, :self.n_keys]
         return res
 
+    def classify_concat(self, gene_len, gene_rows, src_row, want_bits=False):
+        """classify_genome.py:364-388 + :494 on the GPU: gene_len[p] features and packed rows
+        gene_rows[p] (uint32 [n_p, W_p]) per marker gene, src_row int32 [n_genomes, n_genes] = the
+        row of gene p that belongs to genome j or -1 (zero-filled).  Returns the BatchResult of the
+        concatenated rows against this (concatenated) database."""
+        n_genes = len(gene_len)
+        src = np.ascontiguousarray(src_row, dtype=np.int32).reshape(-1, n_genes)
+        n = src.shape[0]
+        rows = [np.ascontiguousarray(r, dtype=np.uint32).reshape(len(r), -1) if len(r) else
+                np.zeros((0, 4), dtype=np.uint32) for r in gene_rows]
+        glen = np.ascontiguousarray(gene_len, dtype=np.int32)
+        wpr = np.array([r.shape[1] for r in rows], dtype=np.int32)
+        nrows = np.array([r.shape[0] for r in rows], dtype=np.int64)
+        ptrs = (ctypes.c_void_p * n_genes)(*[r.ctypes.data if r.size else None for r in rows])
+        res = BatchResult(n, self.max_depth, self.n_keys)
+        st = res.as_struct()
+        if want_bits:
+            res.bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
+        _lib.check(_lib.lib().stag_classify_concat(self.handle, n_genes, _lib.ptr(glen), ptrs, _lib.ptr(wpr), _lib.ptr(nrows),
+                                                   _lib.ptr(src), n, ctypes.byref(st), _lib.ptr(res.bits)))
+        res.level_prob = res.level_prob[:, :self.n_keys]
+        return res
+
     # ------------------------------------------------------------------ profiling (bench.py)
     def profile_enable(self, on=True):
         _lib.check(_lib.lib().stag_profile_enable(self.handle, int(bool(on))))

@@ -44,6 +44,19 @@ class OracleDatabase(Database):
         strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(len(offs) - 1)]
         return self.classify_a2m(strings, min_perc_state, want_bits)
 
+    def classify_concat(self, gene_len, gene_rows, src_row, want_bits=False):
+        from stag_amd.tables import pack_bool_rows
+        src = np.asarray(src_row).reshape(-1, len(gene_len))
+        X = np.zeros((src.shape[0], self.n_features), dtype=bool)
+        at = 0
+        for p, g in enumerate(gene_len):
+            ok = src[:, p] >= 0
+            if ok.any():
+                X[ok, at:at + g] = unpack_rows(np.asarray(gene_rows[p]), g)[src[ok, p]]
+            at += g
+        assert at == self.n_features
+        return self.classify_bits(pack_bool_rows(X, self.words_per_row))
+
     def classify_protein_a2m_text(self, ptext, poffs, gtext, goffs, min_perc_state=0.0, want_bits=False):
         n = len(poffs) - 1
         cut = lambda t, o, i: bytes(t[o[i]:o[i + 1]]).decode("latin-1")

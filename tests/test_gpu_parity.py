@@ -407,3 +407,46 @@ def test_classify_protein_a2m_equals_host_backtranslation(capfd):
         with pytest.raises(TypeError):
             raise_for_status(res.status)
     capfd.readouterr()
+
+
+def test_classify_concat_equals_host_concatenation():
+    """classify_genome.py:364-388 on the GPU: concatenated rows == np.concatenate of the genes'
+    rows (zeros for a missing gene), and their classification == classify_bits on those rows."""
+    rng = np.random.default_rng(55)
+    gene_len = [45, 100, 32, 5, 330, 64, 0, 95, 129]          # odd bit offsets, a 5-bit and an empty gene
+    L = sum(gene_len)
+    assert L % 5 == 0
+    taxonomy, tax_function, classifiers = random_db(rng, L // 5, [[3], [2, 2, 2]], 0.15)
+    n_genomes = 300
+    gene_rows, dense = [], []
+    for g in gene_len:
+        m = int(rng.integers(0, 2 * n_genomes))
+        X = rng.random((m, g)) < 0.3
+        dense.append(X)
+        gene_rows.append(tables.pack_bool_rows(X, tables.words_per_row(g)) if m else np.zeros((0, 4), dtype=np.uint32))
+    src = np.full((n_genomes, len(gene_len)), -1, dtype=np.int32)
+    for p, X in enumerate(dense):
+        if len(X):
+            have = rng.random(n_genomes) < 0.8
+            src[have, p] = rng.integers(0, len(X), size=int(have.sum()))
+    src[7] = -1                                               # a genome without any gene: all zeros
+    want = np.zeros((n_genomes, L), dtype=bool)
+    at = 0
+    for p, g in enumerate(gene_len):
+        rows = src[:, p]
+        ok = rows >= 0
+        want[ok, at:at + g] = dense[p][rows[ok]]
+        at += g
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        res = db.classify_concat(gene_len, gene_rows, src, want_bits=True)
+        assert np.array_equal(tables.unpack_rows(res.bits, L), want)
+        assert not res.bits.view(np.uint8)[:, (L + 7) // 8:].any() or L % 8      # padding words stay zero
+        ref = db.classify_onehot(want)
+        for f in ("status", "n_aligned", "path_len", "selected", "n_lead_single", "path_node", "path_prob", "level_prob"):
+            assert np.array_equal(getattr(res, f), getattr(ref, f)), f
+        with pytest.raises(_lib.StagError):                   # lengths must add up to the database's L
+            db.classify_concat(gene_len[:-1], gene_rows[:-1], src[:, :-1])
+        bad = src.copy()
+        bad[3, 0] = len(dense[0])
+        with pytest.raises(_lib.StagError):
+            db.classify_concat(gene_len, gene_rows, bad)

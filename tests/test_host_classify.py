@@ -172,6 +172,78 @@ def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_pa
         sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o3"))
 
 
+def test_classify_genome_fused_concat_equals_text_path(fake_gpu, monkeypatch, tmp_path):
+    """classify_genome -G end to end (marker-gene DBs, MG_ali, genes_predictions, genome_annotation):
+    the concatenated rows assembled from the packed marker-gene rows give byte for byte the
+    genome_annotation of the reference's text round trip (concat_alignments, pinned by concat.json)."""
+    rng = np.random.default_rng(12)
+    ncols = {"COG0012": 6, "COG0016": 9, "COG0018": 3}
+    order = list(ncols)
+
+    def make_db(L):
+        tax = {"tree_root": ["d_A", "d_B"], "d_A": ["p_A1", "p_A2"], "d_B": ["p_B1"], "p_A1": [], "p_A2": [], "p_B1": []}
+        cls = {k: rng.normal(0, 1, size=1 + L) for k in ("d_A", "d_B", "p_A1", "p_A2")}
+        cls["p_B1"] = "no_negative_examples"
+        tf = {str(k): rng.normal(0, 1, size=3) for k in (-1, 0, 1)}
+        return tax, tf, cls
+
+    dbs = {mg: make_db(5 * c) for mg, c in ncols.items()}
+    dbs["concat"] = make_db(5 * sum(ncols.values()))
+
+    def fake_load_db(path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):
+        hmm = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        hmm.close()
+        tax, tf, cls = dbs[os.path.basename(path)]
+        return hmm.name, False, tax, tf, dict(cls), "0.8.2"
+
+    def fake_load_genome_DB(database, tool_version, verbose):
+        d = tempfile.mkdtemp()
+        return ({mg: os.path.join(d, mg) for mg in order}, d, {mg: "10" for mg in order}, order,
+                {mg: str(5 * c) for mg, c in ncols.items()}, os.path.join(d, "concat"))
+
+    monkeypatch.setattr(sc, "load_db", fake_load_db)
+    monkeypatch.setattr(scg, "load_genome_DB", fake_load_genome_DB)
+    monkeypatch.setattr(scg.os.path, "isfile", lambda p: True if os.path.basename(p) in ncols else os.path.exists(p))
+    # marker genes: genomeA has all three (two copies of COG0016: the last one wins), genomeB lacks COG0018,
+    # genomeC only has COG0018
+    have = {"COG0012": ["genomeA_1", "genomeB_4"], "COG0016": ["genomeA_2", "genomeB_9", "genomeA_7"],
+            "COG0018": ["genomeC_3", "genomeA_5"]}
+    mgs = {}
+    for mg, ids in have.items():
+        fna = tmp_path / (mg + ".fna")
+        fna.write_text("".join(">%s##%s\nACGT\n" % (i, mg) for i in ids))
+        (tmp_path / (mg + ".fna.a2m")).write_text("".join(
+            ">%s##%s\n%s\n" % (i, mg, "".join(rng.choice(list("ACGT-"), size=ncols[mg]))) for i in ids))
+        mgs[mg] = [str(fna), "no_protein"]
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    # classify_genome copies the marker genes to MG_sequences/ first: look the replay up by file name
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s/$(basename $2).a2m\n" % tmp_path)
+    (bindir / "esl-reformat").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat\n")
+    for t in ("hmmalign", "esl-reformat"):
+        os.chmod(bindir / t, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    spec = tmp_path / "mgs.json"
+    spec.write_text(json.dumps(mgs))
+
+    fused = tmp_path / "fused"
+    scg.classify_genome("genomedb", marker_genes=[str(spec)], output=str(fused), verbose=1, long_out=True)
+    used = []
+    real = scg.concat_on_device
+    monkeypatch.setattr(scg, "concat_on_device", lambda *a: used.append(real(*a)) or None)
+    text = tmp_path / "text"
+    scg.classify_genome("genomedb", marker_genes=[str(spec)], output=str(text), verbose=1, long_out=True)
+    src = used[0]
+    assert src["ids"] == ["genomeA", "genomeB", "genomeC"]
+    assert src["src_row"].tolist() == [[0, 2, 1], [1, 1, -1], [-1, -1, 0]]
+    a = (fused / "genome_annotation").read_text()
+    b = (text / "genome_annotation").read_text()
+    assert a == b and len(a.splitlines()) == 4
+    for sub in ("MG_ali", "genes_predictions"):
+        for f in os.listdir(text / sub):
+            assert (fused / sub / f).read_bytes() == (text / sub / f).read_bytes()
+
+
 def test_parse_onehot_line_matches_reference_reader():
     for line in ("id1\t0\t1\t0\t0\t1\n", "id2\t0\t10\t0\t-3\t1\n", "id3\t1\n", "x y\t0\t0\n"):
         gid, x = sc.parse_onehot_line(line)
