@@ -84,3 +84,80 @@ def test_c2_full_size_properties(c2):
         np.testing.assert_allclose(res.path_prob[pick], out["path_prob"], rtol=1e-9, atol=0)
         np.testing.assert_allclose(res.level_prob[pick], out["level_prob"], rtol=1e-9, atol=0)
         assert np.array_equal(out["selected"], res.selected[pick])
+
+
+def dense_from_text(text, offs, idx, L):
+    return np.stack([oracle_c.encode_a2m(bytes(text[offs[i]:offs[i + 1]]).decode("latin-1"))[0] for i in idx])
+
+
+def test_c3_shape_full_length_reads():
+    """BASELINE configs[2] shape (protein-derived database: ncol 1050, reads cover every column, so
+    no row equals the all-gaps row anywhere and the walk stages full rows), 200k reads."""
+    wl = bw.make_db(3, 1050, [4, 12, 40, 120, 300, 600, 900], 0.02, name="C3")
+    n = 200_000
+    text, offs, leaf = bw.make_reads(wl, seed=31, n=n, window=1050)
+    t = wl.tables
+    with Database(t) as db:
+        res = run(db, text, offs)
+        assert (res.status == 0).all()
+        cf = t.child_first.astype(np.int64)
+        prev = np.zeros(n, dtype=np.int64)
+        for d in range(db.max_depth):
+            node = res.path_node[:, d].astype(np.int64)
+            assert ((node >= cf[prev]) & (node < cf[prev + 1])).all()
+            prev = node
+        is_nt = np.isin(text[:offs[-1]], np.frombuffer(b"ACGTU", dtype=np.uint8))
+        csum = np.concatenate([[0], np.cumsum(is_nt)])
+        assert np.array_equal(res.n_aligned, (csum[offs[1:]] - csum[offs[:-1]]).astype(np.int32))
+        res2 = run(db, text, offs)
+        for f in ("path_node", "path_prob", "level_prob", "selected"):
+            assert np.array_equal(getattr(res, f), getattr(res2, f)), f
+        rng = np.random.default_rng(8)
+        idx = rng.permutation(np.repeat(rng.integers(0, n, size=20_000), 2))
+        sub = run(db, text, offs, idx)
+        for f in ("path_node", "path_prob", "level_prob", "selected"):
+            assert np.array_equal(getattr(sub, f), getattr(res, f)[idx]), f
+        assert (res.path_node[:, db.max_depth - 1] == leaf).mean() > 0.2     # chance would be 1e-3
+        pick = rng.choice(n, size=600, replace=False)
+        out = oracle_c.DenseDB.from_packed(t).classify(dense_from_text(text, offs, pick, t.n_features))
+        assert np.array_equal(out["path_node"], res.path_node[pick])
+        np.testing.assert_allclose(res.path_prob[pick], out["path_prob"], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(res.level_prob[pick], out["level_prob"], rtol=1e-9, atol=0)
+
+
+def test_c4_shape_concatenated_genome_rows():
+    """BASELINE configs[3] shape: the concatenated database of 30 marker genes (L = 30 x 5,250 =
+    157,500 features, 4,924 words per row, 308 coefficient chunks), genomes lacking some genes
+    (zero-filled blocks, classify_genome.py:375).  Encode at that width, then classify."""
+    from stag_amd import tables
+    n_genes, gcol = 30, 1050
+    ncol = n_genes * gcol
+    L = 5 * ncol
+    wl = bw.make_db(4, ncol, [3, 6, 12, 24, 40, 60, 80], 0.02, name="C4")
+    n = 2000
+    text, offs, leaf = bw.make_reads(wl, seed=41, n=n, window=ncol, max_ins=0)
+    t = wl.tables
+    rng = np.random.default_rng(9)
+    with Database(t) as db:
+        assert db.words_per_row == 4924
+        full = db.classify_a2m_text(text, offs, want_bits=True)
+        assert (full.status == 0).all()
+        pick = rng.choice(n, size=40, replace=False)
+        Xp = dense_from_text(text, offs, pick, L)
+        assert np.array_equal(tables.unpack_rows(full.bits[pick], L), Xp)
+        # genomes lacking genes: zero the 5,250-feature block of every missing gene
+        X = tables.unpack_rows(full.bits, L)
+        missing = rng.random((n, n_genes)) < 0.1
+        X &= ~np.repeat(missing, 5 * gcol, axis=1)
+        res = db.classify_onehot(X)
+        assert (res.status == 0).all()
+        res2 = db.classify_onehot(X[::-1].copy())
+        for f in ("path_node", "path_prob", "level_prob", "selected", "n_aligned"):
+            assert np.array_equal(getattr(res2, f), getattr(res, f)[::-1]), f
+        assert np.array_equal(res.n_aligned, (ncol - X[:, 0::5].sum(axis=1)).astype(np.int32))
+        pick = rng.choice(n, size=150, replace=False)
+        out = oracle_c.DenseDB.from_packed(t).classify(X[pick])
+        assert np.array_equal(out["path_node"], res.path_node[pick])
+        np.testing.assert_allclose(res.path_prob[pick], out["path_prob"], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(res.level_prob[pick], out["level_prob"], rtol=1e-9, atol=0)
+        assert np.array_equal(out["selected"], res.selected[pick])
