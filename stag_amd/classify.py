@@ -16,8 +16,8 @@ import time
 import numpy as np
 
 from . import __version__ as tool_version
-from . import _lib, align, ingest, parallel
-from .databases import load_db
+from . import _lib, align, ingest, parallel, table_cache
+from .databases import load_db, open_stagdb
 from .engine import Database, raise_for_status
 from .tables import pack_db
 
@@ -86,10 +86,18 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
     save_ali_to_file) and `concat_source` (marker-gene rows to concatenate on the GPU instead of
     reading aligned_sequences; see classify_genome.concat_on_device)."""
     t0 = time.time()
-    loaded = load_db(database, protein_fasta_input=protein_fasta_input, aligned_sequences=aligned_sequences)
-    hmm_file_path, use_cmalign, taxonomy, tax_function, classifiers, db_tool_version = loaded
-    tables = pack_db(taxonomy, tax_function, classifiers)
-    del classifiers
+    cached = table_cache.load(database, protein_fasta_input, aligned_sequences)
+    if cached is not None:
+        hmm_file_path, use_cmalign, tables, db_tool_version = cached
+    else:
+        loaded = load_db(database, protein_fasta_input=protein_fasta_input, aligned_sequences=aligned_sequences)
+        hmm_file_path, use_cmalign, taxonomy, tax_function, classifiers, db_tool_version = loaded
+        tables = pack_db(taxonomy, tax_function, classifiers)
+        del classifiers
+        if table_cache.cache_dir() and os.path.isfile(database):
+            with open_stagdb(database) as db_in:
+                use_proteins = bool(db_in.read("align_protein")[0])
+            table_cache.store(database, tables, hmm_file_path, use_cmalign, use_proteins, db_tool_version)
     db = Database(tables, device=parallel.local_device() if device is None else device)
     world, rank = parallel.world_rank()
     time_after_loading = time.time()

@@ -3,6 +3,7 @@ import sys
 
 import pytest
 
+os.environ.setdefault("STAG_AMD_CACHE", "off")      # tests leave nothing in ~/.cache; the cache test sets its own
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

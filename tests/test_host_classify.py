@@ -274,6 +274,24 @@ def test_classify_on_reference_written_stagdb(fake_gpu, tmp_path):
     assert open(out).read().splitlines()[0].split("\t") == sc.OUT_HEADER
 
 
+@pytest.mark.skipif(databases._load_h5lib() is None, reason="libstag_h5.so not built")
+def test_classify_uses_the_packed_table_cache(fake_gpu, monkeypatch, tmp_path):
+    monkeypatch.setenv("STAG_AMD_CACHE", str(tmp_path / "cache"))
+    x = np.zeros(145, dtype=bool)
+    x[5 * np.arange(29) + 2] = True
+    ali = tmp_path / "a.tsv"
+    ali.write_text("r0\t%s\n" % "\t".join("1" if b else "0" for b in x))
+    first = sc.classify(TINY, aligned_sequences=str(ali), output=str(tmp_path / "o1"), long_out=True, verbose=1)
+    assert len(os.listdir(tmp_path / "cache")) == 1
+
+    def no_load(*a, **k):
+        raise AssertionError("load_db called although the packed tables are cached")
+
+    monkeypatch.setattr(sc, "load_db", no_load)
+    second = sc.classify(TINY, aligned_sequences=str(ali), output=str(tmp_path / "o2"), long_out=True, verbose=1)
+    assert first == second and open(tmp_path / "o1").read() == open(tmp_path / "o2").read()
+
+
 def test_concat_and_merge_match_reference(tmp_path):
     g = gu.load("concat.json")
     ali = tmp_path / "MG_ali"

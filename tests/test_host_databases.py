@@ -93,3 +93,31 @@ def test_load_genome_db_layout(tmp_path):
             t.add(src / f, arcname=f)
     with pytest.raises(ValueError, match="threshold_file.tsv is missing"):
         databases.load_genome_DB(str(tar))
+
+
+@needs_reader
+def test_packed_table_cache_round_trip(tmp_path, monkeypatch):
+    """classify() packs a .stagDB once; the second load comes from the .npz and is identical."""
+    import shutil
+    from stag_amd import table_cache, tables
+    monkeypatch.setenv("STAG_AMD_CACHE", str(tmp_path / "cache"))
+    db = tmp_path / "copy.stagDB"
+    shutil.copy(TINY, db)
+    assert table_cache.load(str(db)) is None
+    hmm, use_cmalign, taxonomy, tax_function, classifiers, version = databases.load_db(str(db))
+    t = tables.pack_db(taxonomy, tax_function, classifiers)
+    assert table_cache.store(str(db), t, hmm, use_cmalign, False, version)
+    hmm2, cm2, t2, v2 = table_cache.load(str(db))
+    assert open(hmm2).read() == open(hmm).read() and cm2 == use_cmalign and v2 == version
+    assert t2.names == t.names and t2.keys == t.keys and t2.n_features == t.n_features
+    for f in ("child_first", "row_kind", "intercept", "row_off", "row_feat", "row_w", "tf"):
+        a, b = getattr(t, f), getattr(t2, f)
+        assert a.dtype == b.dtype and np.array_equal(a, b), f
+    with pytest.raises(ValueError, match="constructed on genes"):       # databases.py:56-59 still applies
+        table_cache.load(str(db), protein_fasta_input="x.faa")
+    os.utime(db, ns=(1, 1))                                              # a changed file is a different entry
+    assert table_cache.load(str(db)) is None
+    monkeypatch.setenv("STAG_AMD_CACHE", "off")
+    assert table_cache.cache_dir() is None and not table_cache.store(str(db), t, hmm, use_cmalign, False, version)
+    os.remove(hmm)
+    os.remove(hmm2)
