@@ -270,8 +270,16 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         if (live && w < W) {
             v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
             *reinterpret_cast<uint4 *>(dst + w) = v;
-            differs = ((v.x ^ r0_word(w, L)) | (v.y ^ r0_word(w + 1, L)) | (v.z ^ r0_word(w + 2, L)) |
-                       (v.w ^ r0_word(w + 3, L))) != 0u;
+            if ((int64_t)(w + 4) * 32 <= L) {
+                // four whole words of R0 at once: 32 = 2 and 64 = 4 (mod 5), so words w, w+1 are the
+                // 64-bit pattern shifted by s and words w+2, w+3 the same pattern shifted by s+1 (mod 5)
+                const int s5 = (5 - (2 * w) % 5) % 5;
+                const uint64_t r01 = 0x1084210842108421ull << s5, r23 = 0x1084210842108421ull << (s5 == 4 ? 0 : s5 + 1);
+                differs = ((((uint64_t)v.y << 32 | v.x) ^ r01) | (((uint64_t)v.w << 32 | v.z) ^ r23)) != 0ull;
+            } else {
+                differs = ((v.x ^ r0_word(w, L)) | (v.y ^ r0_word(w + 1, L)) | (v.z ^ r0_word(w + 2, L)) |
+                           (v.w ^ r0_word(w + 3, L))) != 0u;
+            }
         }
         unsigned long long d = __ballot(differs);
         if (G < 64) d = (d >> (grp * G)) & ((1ull << G) - 1ull);   // this record's lanes only
