@@ -103,13 +103,13 @@ __device__ __forceinline__ uint32_t r0_word(int w, int L) {
     return v;
 }
 
-// ORs a lane's k 5-bit groups (lo: bits 0..63, hi: bits 64..79) into its record's LDS row at
-// column running + before; returns running + the record's total for this step.
-__device__ __forceinline__ int emit_groups(uint32_t *row, int W, int lane, int G, int running, int before, int k,
-                                           uint64_t lo, uint32_t hi) {
-    // every lane of a group needs the group's total: the inclusive sum of its last lane
-    const int total = __shfl(before + k, (lane & ~(G - 1)) + G - 1);
-    const int64_t bitoff = 5ll * (running + before);
+// The record's LDS row starts as R0 (every column a gap).  A lane XORs in, for each of its k
+// columns, (one-hot group ^ gap group) at column running + before: zero for a gap, so lanes and
+// steps that only see gaps touch nothing.  lo: bits 0..63, hi: bits 64..79 of the k groups.
+// w_lo / w_hi track the words this lane changed (the row's window comes from them).
+__device__ __forceinline__ void emit_groups(uint32_t *row, int W, int col, uint64_t lo, uint32_t hi, int &w_lo, int &w_hi) {
+    if ((lo | hi) == 0ull) return;
+    const int64_t bitoff = 5ll * col;
     const int word0 = (int)(bitoff >> 5);
     const int sh = (int)(bitoff & 31);
     const uint64_t a = lo << sh;
@@ -118,8 +118,11 @@ __device__ __forceinline__ int emit_groups(uint32_t *row, int W, int lane, int G
     const uint32_t v4[4] = {(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)bb, (uint32_t)(bb >> 32)};
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-        if (v4[i] && word0 + i < W) atomicOr(&row[word0 + i], v4[i]);
-    return running + total;
+        if (v4[i] && word0 + i < W) {
+            atomicXor(&row[word0 + i], v4[i]);
+            w_lo = min(w_lo, word0 + i);
+            w_hi = max(w_hi, word0 + i + 1);
+        }
 }
 
 // G = lanes per record (16, 32 or 64): a wave encodes 64/G records side by side, each lane
@@ -146,7 +149,20 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t seq = ((int64_t)blockIdx.x * 4 + wave) * RPW + grp;
     const bool live = seq < n;
     uint32_t *row = s_enc + (size_t)(wave * RPW + grp) * W;
-    for (int w = gl; w < W; w += G) row[w] = 0;
+    for (int w = gl * 4; w < W; w += 4 * G) {   // the row starts as R0: all gaps (W is a multiple of 4)
+        uint32_t r[4];
+        if ((int64_t)(w + 4) * 32 <= L) {
+            const int s5 = (5 - (2 * w) % 5) % 5;
+            const uint64_t r01 = 0x1084210842108421ull << s5, r23 = 0x1084210842108421ull << (s5 == 4 ? 0 : s5 + 1);
+            r[0] = (uint32_t)r01; r[1] = (uint32_t)(r01 >> 32); r[2] = (uint32_t)r23; r[3] = (uint32_t)(r23 >> 32);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = r0_word(w + j, L);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) row[w + j] = r[j];
+    }
+    int w_lo = 0x7fffffff, w_hi = 0;     // words this lane changes
 
     const int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
     const int64_t base = begin & ~(int64_t)15;
@@ -182,17 +198,9 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         const bool all_gap = ((((wv[0] ^ 0x2d2d2d2du) & keep[0]) | ((wv[1] ^ 0x2d2d2d2du) & keep[1]) |
                                ((wv[2] ^ 0x2d2d2d2du) & keep[2]) | ((wv[3] ^ 0x2d2d2d2du) & keep[3])) == 0u);
         if (__ballot(!all_gap) == 0ull) {
-            const int k = max(hi_cut - lo_cut, 0);
-            const uint64_t lo = 5 * k >= 64 ? 0x1084210842108421ull : (0x1084210842108421ull & ((1ull << (5 * k)) - 1ull));
-            const uint32_t hi = 0x842u & ((1u << max(5 * k - 64, 0)) - 1u);
-            int v = k;
-            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
-            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
-            if (G >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
-            if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
-            running = emit_groups(row, W, lane, G, running, v - k, k, lo, hi);
+            // the row already says "gap" everywhere: only the column count moves on, by the bytes
+            // of this step that belong to the record
+            running += (int)max((int64_t)0, min(end, p0 + 16 * G) - max(begin, p0));
             continue;
         }
 #pragma unroll
@@ -215,12 +223,12 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             const uint32_t y = x ^ expc;
             const uint32_t eq80 = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;  // byte == expected
             const uint32_t eqm = (eq80 >> 7) * 0xffu;
-            code[j] = (oneh & eqm) | (0x01010101u & ~eqm);
+            code[j] = (oneh ^ 0x01010101u) & eqm;   // group ^ gap group: zero for anything that is not A/C/G/T/U
             aligned += __popc(eq80);
         }
         uint64_t lo;
         uint32_t hi;
-        int k, before;   // groups this lane emits, groups emitted by the lanes before it in the record
+        int before, total;   // groups emitted by the lanes before this one in the record, and by the whole record
         if (__ballot((skip80[0] | skip80[1] | skip80[2] | skip80[3]) != 0u) == 0ull) {
             // no insert / line break anywhere in this step: byte j is column j, positions are static
             uint32_t pk[4];
@@ -229,8 +237,8 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                 pk[j] = (code[j] & 0x1fu) | ((code[j] >> 3) & 0x3e0u) | ((code[j] >> 6) & 0x7c00u) | ((code[j] >> 9) & 0xf8000u);
             lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << 20) | ((uint64_t)pk[2] << 40) | ((uint64_t)pk[3] << 60);
             hi = pk[3] >> 4;
-            k = 16;
             before = 16 * gl;
+            total = 16 * G;
         } else {
             // pack the kept bytes' 5-bit groups densely (a skipped byte contributes no group)
             uint32_t pk[4];
@@ -247,7 +255,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
             lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) | ((uint64_t)pk[3] << sh3);
             hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
-            k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
+            const int k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
             // inclusive prefix sum inside each record's lane group (DPP: rows of 16, then row carries)
             int v = k;
             v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
@@ -257,36 +265,39 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             if (G >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
             if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
             before = v - k;
+            total = __shfl(v, (lane & ~(G - 1)) + G - 1);   // the inclusive sum of the group's last lane
         }
-        running = emit_groups(row, W, lane, G, running, before, k, lo, hi);
+        emit_groups(row, W, running + before, lo, hi, w_lo, w_hi);
+        running += total;
     }
 #pragma unroll
     for (int d = G / 2; d > 0; d >>= 1) aligned += __shfl_xor(aligned, d);   // stays inside the group
     uint32_t *dst = rows + (size_t)(live ? seq : 0) * W;
+    // the window = the words some lane of the record changed (everything else still equals R0)
+#pragma unroll
+    for (int d = G / 2; d > 0; d >>= 1) {
+        w_lo = min(w_lo, __shfl_xor(w_lo, d));
+        w_hi = max(w_hi, __shfl_xor(w_hi, d));
+    }
     int lo4 = 0xffff, hi4 = 0;
-    for (int w = gl * 4, it = 0; it * 4 * G < W; w += 4 * G, ++it) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        bool differs = false;
-        if (live && w < W) {
-            v.x = row[w]; v.y = row[w + 1]; v.z = row[w + 2]; v.w = row[w + 3];
-            *reinterpret_cast<uint4 *>(dst + w) = v;
-            if ((int64_t)(w + 4) * 32 <= L) {
-                // four whole words of R0 at once: 32 = 2 and 64 = 4 (mod 5), so words w, w+1 are the
-                // 64-bit pattern shifted by s and words w+2, w+3 the same pattern shifted by s+1 (mod 5)
-                const int s5 = (5 - (2 * w) % 5) % 5;
-                const uint64_t r01 = 0x1084210842108421ull << s5, r23 = 0x1084210842108421ull << (s5 == 4 ? 0 : s5 + 1);
-                differs = ((((uint64_t)v.y << 32 | v.x) ^ r01) | (((uint64_t)v.w << 32 | v.z) ^ r23)) != 0ull;
-            } else {
-                differs = ((v.x ^ r0_word(w, L)) | (v.y ^ r0_word(w + 1, L)) | (v.z ^ r0_word(w + 2, L)) |
-                           (v.w ^ r0_word(w + 3, L))) != 0u;
+    if (w_hi > w_lo) { lo4 = w_lo >> 2; hi4 = (w_hi + 3) >> 2; }
+    // a record with fewer columns than the database has no bits past its last column (it is
+    // reported as LENGTH_MISMATCH and never classified; the row is still what align.py:37-58 gives)
+    const int64_t valid_bits = 5ll * running;
+    const bool short_row = valid_bits < (int64_t)L;
+    if (short_row) { lo4 = 0; hi4 = W >> 2; }
+    for (int w = gl * 4; w < W; w += 4 * G) {
+        if (!live) break;
+        uint32_t v[4] = {row[w], row[w + 1], row[w + 2], row[w + 3]};
+        if (short_row) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int64_t nb = valid_bits - 32ll * (w + j);
+                if (nb <= 0) v[j] = 0u;
+                else if (nb < 32) v[j] &= (1u << nb) - 1u;
             }
         }
-        unsigned long long d = __ballot(differs);
-        if (G < 64) d = (d >> (grp * G)) & ((1ull << G) - 1ull);   // this record's lanes only
-        if (d) {
-            lo4 = min(lo4, it * G + (int)__ffsll((long long)d) - 1);
-            hi4 = max(hi4, it * G + 64 - (int)__clzll((long long)d));
-        }
+        *reinterpret_cast<uint4 *>(dst + w) = make_uint4(v[0], v[1], v[2], v[3]);
     }
     if (live && gl == 0) {
         if (win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
