@@ -150,12 +150,13 @@ def main():
     total_ms = sum(v[0] for v in prof.values())
     per_step = {k: v[0] / prof_steps for k, v in prof.items()}
     # The dominant kernel is whichever class takes most device time per step.  Algorithmic bytes
-    # per launch: encode reads the text and produces the one-hot, credited
-    # as B_seq's "A + ncol"; the walk (D launches per step) gets the rest of B_seq's row/result
-    # term spread over its launches.
+    # per launch are each kernel's own minimum in SURVEY 8d's terms: encode
+    # reads the text (A) and writes the encoded form (ncol); the walk reads the encoded form once
+    # (ncol) and writes the results (R), spread over its D launches.  (Their sum exceeds B_seq by
+    # ncol: B_seq counts the intermediate once; roofline.path prices the whole step with B_seq.)
     shares = {
         "encode": ("k_encode_a2m", n * (A + ncol), 1),
-        "walk_level": ("k_walk_level", n * R / D, D),
+        "walk_level": ("k_walk_level", n * (ncol + R) / D, D),
     }
     dom = max(shares, key=lambda c: per_step[c])
     kname, bytes_per_launch, launches_per_step = shares[dom]
