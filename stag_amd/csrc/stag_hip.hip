@@ -84,7 +84,7 @@ struct stag_db {
     DevBuf<LevelRec> lvl;
     DevBuf<Task> tasks;
     DevBuf<uint32_t> bits, win;
-    DevBuf<double> chunkgap;
+    DevBuf<double> gappre, gapsuf;
     DevBuf<uint8_t> text, gene_text, bt_text;
     DevBuf<int64_t> offs, gene_offs, bt_begin, bt_end;
     DevBuf<int32_t> bt_status;
@@ -100,7 +100,7 @@ struct stag_db {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
         count.release(); lvl.release(); task_off.release(); n_tasks.release(); tasks.release();
-        bits.release(); win.release(); chunkgap.release(); text.release(); offs.release();
+        bits.release(); win.release(); gappre.release(); gapsuf.release(); text.release(); offs.release();
         gene_text.release(); bt_text.release(); gene_offs.release(); bt_begin.release(); bt_end.release(); bt_status.release(); enc_n_char.release(); enc_status.release();
         r_path_node.release(); r_path_len.release(); r_lead.release(); r_selected.release();
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
@@ -278,7 +278,7 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
         a.intercept = db->intercept.p;
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p;
         a.lvl = cur; a.status = o.status;
-        a.chunkgap = db->chunkgap.p;
+        a.gappre = db->gappre.p; a.gapsuf = db->gapsuf.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
             Prof p(db, st, 1);
@@ -394,17 +394,18 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
         if (node_err[p]) for (int c = c0; c < c1; ++c) evaluated[c] = 0;
     }
 
-    // coefficient blocks per (row, 16-word chunk) and the per-chunk prefix sums of the
-    // coefficients on "others" bits (feature % 5 == 0): what the all-gaps row R0 scores
+    // coefficient blocks per (row, 16-word chunk) and, per chunk, the sum of the coefficients on
+    // "others" bits (feature % 5 == 0): what the all-gaps row R0 scores there
     const int nch = db->nchunks;
     std::vector<uint32_t> blk_off((size_t)n * nch + 1, 0);
-    std::vector<double> chunkgap((size_t)n * nch + 8, 0.0);   // +8: the kernel fetches 8 at a time
+    std::vector<double> gappre((size_t)n * (nch + 1), 0.0), gapsuf((size_t)n * (nch + 1), 0.0), gaps(nch, 0.0);
     std::vector<Entry> entries;
     for (int c = 0; c < n; ++c) {
         int64_t e = t->row_off[c];
         const int64_t e1 = t->row_off[c + 1];
         if (e1 < e) { delete db; return fail(STAG_E_INVALID, "row_off not monotone at node %d", c); }
         int prev = -1;
+        std::fill(gaps.begin(), gaps.end(), 0.0);
         for (int ch = 0; ch < nch; ++ch) {
             blk_off[(size_t)c * nch + ch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
             if (!evaluated[c]) continue;
@@ -427,8 +428,13 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
             }
             const uint32_t pad_off = 4u * (uint32_t)(ch * CHUNK_WORDS);   // padding reads a staged word
             while (entries.size() % BLOCK_ENTRIES) entries.push_back(Entry{pad_off, 0u, 0.0});
-            chunkgap[(size_t)c * nch + ch] = gap;
+            gaps[ch] = gap;
         }
+        // the two chains the kernel adds to a row's own-window sum (fixed orders: up from chunk 0,
+        // down from the last chunk)
+        double *pre = &gappre[(size_t)c * (nch + 1)], *suf = &gapsuf[(size_t)c * (nch + 1)];
+        for (int ch = 0; ch < nch; ++ch) pre[ch + 1] = pre[ch] + gaps[ch];
+        for (int ch = nch - 1; ch >= 0; --ch) suf[ch] = suf[ch + 1] + gaps[ch];
         if (evaluated[c] && e != e1) { delete db; return fail(STAG_E_INVALID, "row %d: feature out of range", c); }
         if (entries.size() / BLOCK_ENTRIES > 0x7fffffffull) { delete db; return fail(STAG_E_INVALID, "coefficient table too large"); }
     }
@@ -445,7 +451,8 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     std::vector<int32_t> cf(t->child_first, t->child_first + n + 1);
     std::vector<double> ic(t->intercept, t->intercept + n);
     std::vector<double> tfv(t->tf ? t->tf : nullptr, t->tf ? t->tf + (size_t)t->n_keys * (1 + t->n_tf) : nullptr);
-    UP(chunkgap, chunkgap, double);
+    UP(gappre, gappre, double);
+    UP(gapsuf, gapsuf, double);
     UP(child_first, cf, int32_t);
     UP(node_err, node_err, uint8_t);
     UP(intercept, ic, double);

@@ -649,7 +649,9 @@ struct WalkArgs {
     const SeqRef *order;
     const double *intercept;
     const uint32_t *blk_off;    // [n_nodes*NC + 1]
-    const double *chunkgap;     // [n_nodes][NC] (+8 padding): sum of a chunk's coefficients on "others" bits
+    const double *gappre;       // [n_nodes][NC+1]: gap[0] + ... + gap[ch-1], added in that order (gap[ch] = what R0
+                                // scores in chunk ch: the sum of the chunk's coefficients on "others" bits)
+    const double *gapsuf;       // [n_nodes][NC+1]: gap[NC-1] + ... + gap[ch], added in that order
     const uint4 *blocks;        // Entry[4] per block
     LevelRec *lvl;              // [n] this level's records
     int32_t *status;
@@ -662,24 +664,6 @@ __device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 
     const uint32_t x = *reinterpret_cast<const uint32_t *>(my_row + e.x);
     const int m = __builtin_amdgcn_sbfe((int)x, e.y, 1u);  // 0 or -1
     return __hiloint2double((int)e.w & m, (int)e.z & m);
-}
-
-// z += chunkgap[ch] for lo <= ch < hi, in increasing order.  Values arrive 8 at a time through
-// one scalar load (the array is padded).
-__device__ __forceinline__ double add_outside(double z, const double STAG_CONST *cg, int lo, int hi) {
-    for (int g = lo & ~7; g < hi; g += 8) {
-        double d[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) d[j] = cg[g + j];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            // the choice is made on the (wave-uniform) addend, in scalar registers: one v_add_f64
-            // per chunk.  Adding +0.0 changes nothing: z is never -0.0 (it starts at +0.0).
-            const int ch = g + j;
-            z += (ch >= lo && ch < hi) ? d[j] : 0.0;
-        }
-    }
-    return z;
 }
 
 // 64-lane min / max with DPP moves (no LDS traffic); the result is wave-uniform.
@@ -763,10 +747,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 
     // ---- the task's window in chunks [cA, cB): union of its rows' windows
     int lo = 0x7fff, hi = 0;
+    int own_lo = 0, own_hi = 0;   // this lane's own window in chunks (empty: its row is R0 everywhere)
     if (seq >= 0) {
         const uint32_t wn = me.win;
         const int l4 = (int)(wn & 0xffffu), h4 = (int)(wn >> 16);
-        if (h4 > l4) { lo = l4 >> 2; hi = (h4 + 3) >> 2; }   // 4-word units -> 16-word chunks
+        if (h4 > l4) {   // 4-word units -> 16-word chunks
+            lo = own_lo = l4 >> 2;
+            hi = own_hi = min((h4 + 3) >> 2, a.NC);
+        }
     }
     const int cA = wave_min_i(lo);
     const int cB = min(wave_max_i(hi), a.NC);
@@ -776,24 +764,29 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     // the idle waves of a short pass was measured slower: the kernel is bound by instruction
     // issue, not by the length of one wave's chain.)
     //
-    // CANONICAL SUMMATION.  z is one chain over the chunks in increasing order, one term per
-    // chunk: inside the window the lane's own sum over that chunk's coefficients (in stored
-    // order, one accumulator), outside it chunkgap[ch], which the host computed with the same
-    // additions for a row that equals R0 there.  So a score depends only on (row, node): not on
-    // which other rows share the task, nor on how wide the task's window is.  That keeps results
+    // CANONICAL SUMMATION.  A row's OWN window (from its own bits: the chunks in which it differs
+    // from R0) fixes how its score is added up: z = (gappre[own_lo] + gapsuf[own_hi]) -- what R0
+    // scores before and after that window, each a chain the host added up in a fixed order -- plus,
+    // in increasing chunk order, one term per chunk of the own window: the lane's sum over that
+    // chunk's coefficients (in stored order, one accumulator).  Chunks that are inside the task's
+    // window only because of other rows are left out (they are part of the two constants).  So a
+    // score depends only on (row, node): not on which other rows share the task.  That keeps results
     // bit-identical from run to run (task composition comes from atomics) and makes identical
-    // sibling rows tie exactly, so the first stored child wins as in classify.py:41.  (A table of
-    // the chain's prefix sums, one load instead of the loop before the window, measured 20 % slower.)
+    // sibling rows tie exactly, so the first stored child wins as in classify.py:41.
     double best_p = -1.0;
     int best_c = -1;
     const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
     for (int pass0 = 0; pass0 < k; pass0 += NW) {
         const bool active = pass0 + wave < k;
         const int c = c0 + pass0 + wave;
-        const double STAG_CONST *cg = as_const(a.chunkgap) + (size_t)c * a.NC;
         const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
         double z = 0.0;
-        if (active) z = add_outside(z, cg, 0, wA);
+        if (active) {   // two 8-byte gathers per lane; lanes of one task mostly share the addresses
+            const size_t base = (size_t)c * (a.NC + 1);
+            int i_lo = own_lo, i_hi = own_hi;
+            asm volatile("" : "+v"(i_lo), "+v"(i_hi));   // keeps the two 64-bit addresses out of long-lived registers
+            z = a.gappre[base + i_lo] + a.gapsuf[base + i_hi];
+        }
         for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
             const int sB = min(wB, sA + WCAP_CHUNKS);
             // this wave's coefficient range of the slice: contiguous, chunk after chunk
@@ -823,6 +816,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             } else {
                 if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private: LDS operations of one wave stay in order
             }
+            // which chunks of this slice lie in the lane's own window (bit i: chunk sA + i)
+            const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
+                                      ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
             if (active) {
                 // entry offsets are relative to the row; the slice starts at chunk sA
                 const char *my_row = reinterpret_cast<const char *>(s_rows) +
@@ -840,7 +836,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                             cs += masked_weight_v(my_row, n2);
                             cs += masked_weight_v(my_row, n3);
                         }
-                        z += cs;
+                        z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
                     }
                 } else {
                     uint32_t piece = e_lo;   // first entry held in s_ent[wave]
@@ -860,12 +856,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                             cs += masked_weight_v(my_row, n2);
                             cs += masked_weight_v(my_row, n3);
                         }
-                        z += cs;
+                        z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
                     }
                 }
             }
         }
-        if (active) z = add_outside(z, cg, wB, a.NC);
         if (active) {
             const double p = sigmoid(z + as_const(a.intercept)[c]);
             if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
