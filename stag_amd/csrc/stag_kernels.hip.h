@@ -8,12 +8,12 @@
 //   coefficient blocks           each child row's NON-ZERO coefficients, sorted by feature, cut
 //                                into chunks of CHUNK_WORDS = 16 row words (512 features, 64 B of
 //                                a row) and padded per (row, chunk) to blocks of 4 entries
-//                                {byte offset in row, bit, fp64 w} = 64 B = one s_load_dwordx16;
+//                                {byte offset in row, bit, fp64 w} = 64 B;
 //                                blk_off[row * NC + chunk] indexes them
-//   chunk gaps    double[n_nodes][NC]  per chunk, the sum of the coefficients that sit on a column's
-//                                "others" bit: what R0 scores in that chunk
-//   grouping      node[n], pos[n], order[n], tasks[]: sequences sorted by current tree node,
-//                                cut into tasks of <= 64 sequences of one node
+//   gap chains    double[n_nodes][NC+1] x 2  what R0 scores before / from a chunk on (gappre, gapsuf)
+//   grouping      node[n], pos[n], tasks[], order[64 per task]: sequences sorted by current tree
+//                                node, cut into tasks of <= 64 sequences of one node
+//   level records {node, prob}[D][n]  what each level decided for each sequence
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -629,17 +629,18 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
 // `depth`.  One workgroup = up to 64 sequences of ONE node (lane = sequence).
 //
 //  * Only the task's WINDOW of the rows is read: the union of the 64 rows' windows, rounded to
-//    16-word chunks (64-byte sectors).  Outside it every row equals R0, so a sibling's score
-//    there is a constant: the sum of its coefficients on "others" bits, kept per chunk
-//    (chunkgap).  z = intercept + chunkgap(chunks outside the window) + sum over the coefficients
-//    INSIDE the window whose feature bit is set in the lane's row.  For 253-column amplicon
-//    reads in a 1,500-column alignment that is 256 B instead of 944 B per row and a sixth of
-//    the coefficients; for rows that differ from R0 everywhere it degrades to the full row.
+//    16-word chunks (64-byte sectors).  Outside its own window a row equals R0, so what a sibling
+//    scores there is a constant of the sibling (gappre / gapsuf, added up on the host).
+//    z = intercept + that constant + sum over the coefficients INSIDE the row's window whose
+//    feature bit is set in the row.  For 253-column amplicon reads in a 1,500-column alignment
+//    that is 256 B instead of 944 B per row and a sixth of the coefficients; for rows that differ
+//    from R0 everywhere it degrades to the full row.
 //  * The window slice of the rows is staged in LDS ([row][word], odd stride: lane l reading
 //    word w is conflict-free); WCAP_CHUNKS chunks at a time, wider windows loop.
-//  * Sibling rows are dealt to the 8 waves; a wave streams its sibling's coefficient blocks of
-//    the window through scalar loads (one s_load_dwordx16 = 4 coefficients for all 64 lanes)
-//    and every lane adds w & -(bit): v_add, ds_read_b32, v_bfe_i32, 2 x v_and, v_add_f64.
+//  * One wave per sibling, NW siblings per pass.  A wave fetches its sibling's coefficients of
+//    the slice with one 16-byte load per lane into its own piece of LDS and reads them back four
+//    at a time by uniform-address ds_read_b128; per coefficient every lane adds w & -(bit):
+//    v_add, ds_read_b32, v_bfe_i32, 2 x v_and, v_add_f64.
 // ------------------------------------------------------------------------------------------
 struct WalkArgs {
     const uint32_t *bits;       // [n][W]
