@@ -261,7 +261,11 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     for (int d = 0; d < db->max_depth; ++d) {
         const int lo = db->level_start[d], hi = db->level_start[d + 1];
         LevelRec *cur = db->lvl.p + (size_t)d * n;
-        {
+        if (d == 0) {
+            Prof p(db, st, 2);
+            hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, db->win.p, cur,
+                               db->child_first.p, db->node_err.p, db->order.p, db->tasks.p, db->n_tasks.p);
+        } else {
             Prof p(db, st, 2);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
                                n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, db->node.p,

@@ -624,6 +624,32 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
     }
 }
 
+// Level 0 needs no grouping: every sequence whose incoming status is OK stands on the root, so
+// sequence s takes slot s (task s / 64).  Sequences that are not OK keep their slot with seq = -1
+// (the walk treats such lanes as absent) and get their stop record here.
+__global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__restrict__ status_in,
+                                                    int32_t *__restrict__ status, const uint32_t *__restrict__ win,
+                                                    LevelRec *__restrict__ cur, const int32_t *__restrict__ child_first,
+                                                    const uint8_t *__restrict__ node_err, SeqRef *__restrict__ order,
+                                                    Task *__restrict__ tasks, int32_t *__restrict__ n_tasks) {
+    const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (s >= n) return;
+    const int st = status_in ? status_in[s] : 0;
+    status[s] = st;
+    SeqRef ref;
+    ref.seq = st == 0 ? (int32_t)s : -1;
+    ref.win = win[s];
+    order[s] = ref;
+    if (st != 0) cur[s].node = -1;
+    if ((s & (TILE - 1)) == 0) {
+        Task tk;
+        tk.node = 0; tk.pad2 = 0; tk.count = (int32_t)min((int64_t)TILE, n - s); tk.err = node_err[0];
+        tk.c0 = child_first[0]; tk.k = child_first[1] - tk.c0; tk.pad0 = 0; tk.pad1 = 0;
+        tasks[s / TILE] = tk;
+    }
+    if (s == 0) *n_tasks = (int32_t)((n + TILE - 1) / TILE);
+}
+
 // ------------------------------------------------------------------------------------------
 // walk: one tree level.  stag/classify.py:22-52 for all sequences standing at nodes of level
 // `depth`.  One workgroup = up to 64 sequences of ONE node (lane = sequence).
