@@ -167,22 +167,27 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
+    // Positions inside the loop are 32-bit and relative to the record's first byte (a record is
+    // shorter than 2 GB); only the load address is 64-bit.
+    const int len = (int)(end - begin);
+    const int lead = (int)(begin - base);        // bytes of the first vector that precede the record
     // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
     // entirely inside the buffer or entirely outside the record
-    auto load16 = [&](int64_t p, uint32_t (&o)[4]) {
+    auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4]) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (p < end && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
+        if (rel < len && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
     };
     uint32_t nxt[4];
-    load16(base + (int64_t)gl * 16, nxt);
-    for (int64_t p0 = base; __ballot(p0 < end) != 0ull; p0 += 16 * G) {
-        const int64_t p = p0 + (int64_t)gl * 16;
+    int64_t p = base + (int64_t)gl * 16;         // this lane's vector of the current step
+    load16(p, gl * 16 - lead, nxt);
+    for (int rel0 = -lead; __ballot(rel0 < len) != 0ull; rel0 += 16 * G, p += 16 * G) {
+        const int rel = rel0 + gl * 16;          // of the lane's vector; negative only in the first step
         uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
-        load16(p + 16 * G, nxt);   // the next vector is in flight while this one is encoded
+        load16(p + 16 * G, rel + 16 * G, nxt);   // the next vector is in flight while this one is encoded
         // valid bytes of this lane's vector: [lo_cut, hi_cut) (first and last vector of a record)
-        const int lo_cut = (int)min((int64_t)16, max((int64_t)0, begin - p));
-        const int hi_cut = (int)min((int64_t)16, max((int64_t)0, end - p));
+        const int lo_cut = min(16, max(0, -rel));
+        const int hi_cut = min(16, max(0, len - rel));
         uint32_t keep[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         if (lo_cut > 0 || hi_cut < 16) {
 #pragma unroll
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         if (__ballot(!all_gap) == 0ull) {
             // the row already says "gap" everywhere: only the column count moves on, by the bytes
             // of this step that belong to the record
-            running += (int)max((int64_t)0, min(end, p0 + 16 * G) - max(begin, p0));
+            running += max(0, min(len, rel0 + 16 * G) - max(0, rel0));
             continue;
         }
 #pragma unroll
