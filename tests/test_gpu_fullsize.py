@@ -161,3 +161,32 @@ def test_c4_shape_concatenated_genome_rows():
         np.testing.assert_allclose(res.path_prob[pick], out["path_prob"], rtol=1e-9, atol=0)
         np.testing.assert_allclose(res.level_prob[pick], out["level_prob"], rtol=1e-9, atol=0)
         assert np.array_equal(out["selected"], res.selected[pick])
+
+
+def test_wide_levels_use_every_grouping_path():
+    """A tree whose levels have 3, 150, ~21,000 and ~30,000 nodes: grouping goes through the ballot
+    path (<= 32 nodes), the LDS histogram (<= 15,360) and the per-wave path (wider), and the
+    deepest scored level mixes single-child nodes, leaves and siblings (BASELINE config C5 has
+    50,000 nodes).  Every read is compared with the oracle."""
+    wl = bw.make_db(5, 60, [3, 150, 21000, 30000], 0.1, name="wide")
+    t = wl.tables
+    level = [0, 1]                                       # nodes of depth d are [level[d], level[d + 1])
+    while level[-1] < t.n_nodes and t.child_first[level[-1]] > level[-1]:
+        level.append(int(t.child_first[level[-1]]))
+    widths = np.diff(level).tolist()
+    assert widths[:3] == [1, 3] + widths[2:3] and 32 < widths[2] <= 15_360 < widths[3] and t.n_nodes > 50_000
+    n = 60_000
+    text, offs, leaf = bw.make_reads(wl, seed=51, n=n, window=60)
+    with Database(t) as db:
+        assert db.max_depth == 4
+        res = run(db, text, offs)
+        assert (res.status == 0).all()
+        X = dense_from_text(text, offs, np.arange(n), t.n_features)
+        out = oracle_c.DenseDB.from_packed(t).classify(X)
+        assert np.array_equal(out["path_len"], res.path_len)
+        assert np.array_equal(out["path_node"], res.path_node)
+        np.testing.assert_allclose(res.path_prob, out["path_prob"], rtol=1e-9, atol=0)
+        np.testing.assert_allclose(res.level_prob, out["level_prob"], rtol=1e-9, atol=0)
+        assert np.array_equal(out["selected"], res.selected)
+        res2 = run(db, text, offs, np.arange(n)[::-1].copy())
+        assert np.array_equal(res2.path_node, res.path_node[::-1]) and np.array_equal(res2.path_prob, res.path_prob[::-1])
