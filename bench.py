@@ -201,7 +201,7 @@ def main():
                   "max_rel_err_node_prob": float(rel[same_path].max()) if same_path.any() else None,
                   "max_rel_err_level_prob": float(rel_lp[same_path].max()) if same_path.any() else None,
                   "n_aligned_equal": bool((out["n_aligned"][:m].cpu().numpy() == o["n_aligned"]).all())}
-        del odb, X
+        del X
 
     # ---- CPU baseline: the NumPy port (reference cost structure, 1 core) on a bounded sample
     cpu = None
@@ -224,6 +224,43 @@ def main():
                          "reference's cost structure; `stag classify -t N` is single-core on this path); "
                          "host has %d cores" % (sample, os.cpu_count())}
 
+    # ---- "fair CPU" (SURVEY 8d ii): the C restatement (oracle/stag_oracle.c, dense rows, scalar code)
+    # on all the host cores the box gives this job, same reads; reported beside cpu_baseline
+    cpu_c = None
+    if not args.no_cpu_baseline and world == 1 and args.check > 0:
+        from concurrent.futures import ThreadPoolExecutor
+        from oracle import oracle_c
+        threads = max(1, min(16, os.cpu_count() or 1))
+        per = 1500
+        strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(min(n, threads * per))]
+
+        def work(k):
+            part = strings[k * per:(k + 1) * per]
+            Xp = np.stack([oracle_c.encode_a2m(s_)[0] for s_ in part]) if part else np.zeros((0, t.n_features), np.uint8)
+            return len(odb.classify(Xp)["status"]) if len(part) else 0
+
+        c0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            done = sum(ex.map(work, range(threads)))
+        cdt = time.perf_counter() - c0
+        cpu_c = {"value": round(done / cdt, 1), "unit": "seqs/s", "cores": threads, "kind": "port",
+                 "sample": "%d reads through oracle/stag_oracle.c (dense fp64 rows), %d threads" % (done, threads)}
+    if args.check > 0:
+        del odb
+
+    # ---- what a plain device-to-device copy reaches on this GPU (read + write), for the roofline's context
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    dst = torch.empty_like(src)
+    for _ in range(2):
+        dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    c0 = time.perf_counter()
+    for _ in range(5):
+        dst.copy_(src)
+    torch.cuda.synchronize(dev)
+    roofline["measured_copy_GBs"] = round(5 * 2 * src.numel() / (time.perf_counter() - c0) / 1e9, 1)
+    del src, dst
+
     value = n * world * args.steps / dt
     print(json.dumps({
         "metric": "classified seqs/sec post-hmmalign", "value": round(value, 1), "unit": "seqs/s",
@@ -234,7 +271,7 @@ def main():
                    "reads_per_gpu": n, "ncol": ncol, "L": t.n_features, "depth": D, "n_nodes": t.n_nodes,
                    "nnz_coefficients": t.nnz, "table_bytes": db.table_bytes, "classified_ok": n_ok,
                    "sharding": "reads split across ranks, tables replicated, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_c, "parity": parity,
     }))
     if world > 1:
         dist.destroy_process_group()
