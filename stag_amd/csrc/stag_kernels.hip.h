@@ -29,7 +29,7 @@ constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-b
 constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
 constexpr int BLOCK_ENTRIES = 4;  // coefficient lists are padded to 4 entries per (row, chunk)
-static_assert(WCAP_CHUNKS * CHUNK_WORDS <= 64, "a staged slice is one dword per lane and row");
+static_assert(WCAP_CHUNKS * CHUNK_WORDS == 64, "a staged slice is one dword per lane and row: all 64 lanes store into a row of ROW_STRIDE words");
 
 struct Entry {      // 16 bytes
     uint32_t off;   // byte offset of the feature's word inside the row
