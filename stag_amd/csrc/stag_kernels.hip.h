@@ -103,6 +103,39 @@ __device__ __forceinline__ uint32_t r0_word(int w, int L) {
     return v;
 }
 
+// keep[lo_cut * 17 + hi_cut]: byte mask (4 dwords) of the bytes [lo_cut, hi_cut) of a 16-byte vector --
+// the part of a record's first / last vector that belongs to the record.
+struct KeepLut {
+    uint32_t m[17 * 17][4];
+};
+constexpr KeepLut make_keep_lut() {
+    KeepLut t{};
+    for (int lo = 0; lo <= 16; ++lo)
+        for (int hi = 0; hi <= 16; ++hi)
+            for (int j = 0; j < 4; ++j) {
+                const int a0 = lo - 4 * j < 0 ? 0 : lo - 4 * j > 4 ? 4 : lo - 4 * j;
+                const int b0 = hi - 4 * j < 0 ? 0 : hi - 4 * j > 4 ? 4 : hi - 4 * j;
+                const uint32_t below_b = b0 >= 4 ? 0xffffffffu : (1u << (8 * b0)) - 1u;
+                const uint32_t below_a = a0 >= 4 ? 0xffffffffu : (1u << (8 * a0)) - 1u;
+                t.m[lo * 17 + hi][j] = below_b & ~below_a;
+            }
+    return t;
+}
+__device__ const KeepLut KEEP_LUT = make_keep_lut();
+
+// Reductions inside each record's group of G lanes with DPP moves; the result is valid in the
+// group's LAST lane (gl == G - 1).
+template <int G, typename F>
+__device__ __forceinline__ int group_reduce_last(int v, const int identity, F f) {
+    v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    if (G >= 32) v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x142, 0xa, 0xf, false));  // row_bcast:15
+    if (G >= 64) v = f(v, __builtin_amdgcn_update_dpp(identity, v, 0x143, 0xc, 0xf, false));  // row_bcast:31
+    return v;
+}
+
 // The record's LDS row starts as R0 (every column a gap).  A lane XORs in, for each of its k
 // columns, (one-hot group ^ gap group) at column running + before: zero for a gap, so lanes and
 // steps that only see gaps touch nothing.  lo: bits 0..63, hi: bits 64..79 of the k groups.
@@ -173,31 +206,26 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int lead = (int)(begin - base);        // bytes of the first vector that precede the record
     // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
     // entirely inside the buffer or entirely outside the record
-    auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4]) {
+    // also fetches the mask of the vector's bytes that belong to the record: [lo_cut, hi_cut) of 16
+    // (all ones except in a record's first and last vector)
+    auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (rel < len && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        const int lo_cut = min(16, max(0, -rel));
+        const int hi_cut = min(16, max(0, len - rel));
+        uint4 q = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+        if (lo_cut > 0 || hi_cut < 16) q = *reinterpret_cast<const uint4 *>(KEEP_LUT.m[lo_cut * 17 + hi_cut]);
+        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
     };
-    uint32_t nxt[4];
+    uint32_t nxt[4], nxt_keep[4];
     int64_t p = base + (int64_t)gl * 16;         // this lane's vector of the current step
-    load16(p, gl * 16 - lead, nxt);
+    load16(p, gl * 16 - lead, nxt, nxt_keep);
     for (int rel0 = -lead; __ballot(rel0 < len) != 0ull; rel0 += 16 * G, p += 16 * G) {
         const int rel = rel0 + gl * 16;          // of the lane's vector; negative only in the first step
         uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
-        load16(p + 16 * G, rel + 16 * G, nxt);   // the next vector is in flight while this one is encoded
-        // valid bytes of this lane's vector: [lo_cut, hi_cut) (first and last vector of a record)
-        const int lo_cut = min(16, max(0, -rel));
-        const int hi_cut = min(16, max(0, len - rel));
-        uint32_t keep[4] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        if (lo_cut > 0 || hi_cut < 16) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int a0 = min(4, max(0, lo_cut - 4 * j)), b0 = min(4, max(0, hi_cut - 4 * j));
-                const uint32_t below_b = b0 >= 4 ? 0xffffffffu : (1u << (8 * b0)) - 1u;
-                const uint32_t below_a = a0 >= 4 ? 0xffffffffu : (1u << (8 * a0)) - 1u;
-                keep[j] = below_b & ~below_a;
-            }
-        }
+        const uint32_t keep[4] = {nxt_keep[0], nxt_keep[1], nxt_keep[2], nxt_keep[3]};
+        load16(p + 16 * G, rel + 16 * G, nxt, nxt_keep);   // the next vector is in flight while this one is encoded
         // Aligned amplicon reads are mostly runs of '-': when every valid byte of every lane is a
         // gap, the step's output is a prefix of a constant bit pattern (bit 0 of each column).
         const bool all_gap = ((((wv[0] ^ 0x2d2d2d2du) & keep[0]) | ((wv[1] ^ 0x2d2d2d2du) & keep[1]) |
@@ -275,15 +303,12 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         emit_groups(row, W, running + before, lo, hi, w_lo, w_hi);
         running += total;
     }
-#pragma unroll
-    for (int d = G / 2; d > 0; d >>= 1) aligned += __shfl_xor(aligned, d);   // stays inside the group
+    // totals over the record's lanes: valid in the group's last lane, which writes the record's scalars
+    aligned = group_reduce_last<G>(aligned, 0, [](int x, int y) { return x + y; });
     uint32_t *dst = rows + (size_t)(live ? seq : 0) * W;
     // the window = the words some lane of the record changed (everything else still equals R0)
-#pragma unroll
-    for (int d = G / 2; d > 0; d >>= 1) {
-        w_lo = min(w_lo, __shfl_xor(w_lo, d));
-        w_hi = max(w_hi, __shfl_xor(w_hi, d));
-    }
+    w_lo = group_reduce_last<G>(w_lo, 0x7fffffff, [](int x, int y) { return min(x, y); });
+    w_hi = group_reduce_last<G>(w_hi, 0, [](int x, int y) { return max(x, y); });
     int lo4 = 0xffff, hi4 = 0;
     if (w_hi > w_lo) { lo4 = w_lo >> 2; hi4 = (w_hi + 3) >> 2; }
     // a record with fewer columns than the database has no bits past its last column (it is
@@ -304,11 +329,13 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         }
         *reinterpret_cast<uint4 *>(dst + w) = make_uint4(v[0], v[1], v[2], v[3]);
     }
-    if (live && gl == 0) {
+    if (live && gl == G - 1) {
         if (win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
         int st = 0;  // STAG_SEQ_OK
         if (running == 0) st = 5;
-        else if (!((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
+        // min_perc <= 0 (the default of `stag classify`): aligned / running * 100 >= 0 holds for every record
+        // (a NaN threshold still fails every record)
+        else if (!(min_perc <= 0.0) && !((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
         else if ((int64_t)running * 5 != L) st = 7;
         if (pre_status && pre_status[seq]) st = pre_status[seq];
         n_char_out[seq] = running;
