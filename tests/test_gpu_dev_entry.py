@@ -1,0 +1,203 @@
+"""The *_dev entry points of include/stag_hip.h (device buffers in, device results out, the
+caller's stream) against the host-buffer entry points on the same inputs: bit-identical, since
+both run the same kernels.  And stag_classify_a2m_dev recorded into a HIP graph by stream capture
+and replayed: after stag_db_reserve the call only enqueues work on the stream it is given.
+Device memory comes from tests/hipmem.py (ctypes on the HIP runtime libstag_hip.so loaded)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from hipmem import DevArray, hip
+from stag_amd import _lib, tables
+from stag_amd.engine import Database
+from test_gpu_parity import random_db
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("path_node", "path_prob", "path_len", "n_lead_single", "level_prob", "selected", "n_aligned", "status")
+
+
+def device_results(n, D, K):
+    arrs = {
+        "path_node": DevArray(shape=(n, D), dtype=np.int32), "path_prob": DevArray(shape=(n, D), dtype=np.float64),
+        "path_len": DevArray(shape=(n,), dtype=np.int32), "n_lead_single": DevArray(shape=(n,), dtype=np.int32),
+        "level_prob": DevArray(shape=(n, K), dtype=np.float64), "selected": DevArray(shape=(n,), dtype=np.int32),
+        "n_aligned": DevArray(shape=(n,), dtype=np.int32), "status": DevArray(shape=(n,), dtype=np.int32),
+    }
+    res = _lib.Results()
+    for f, _ in _lib.Results._fields_:
+        setattr(res, f, arrs[f].ptr.value)
+    return arrs, res
+
+
+def same_as_host(arrs, ref, n, rows=None):
+    for f in FIELDS:
+        got = arrs[f].get()
+        want = getattr(ref, f)[:n].reshape(got.shape)
+        if rows is not None:
+            got, want = got[rows], want[rows]
+        assert np.array_equal(got, want), f
+
+
+def amplicon_strings(rng, ncol, n):
+    out = []
+    for i in range(n):
+        cols = rng.choice(list("ACGT-N"), size=ncol, p=[0.2, 0.2, 0.2, 0.2, 0.15, 0.05])
+        if i % 4 == 0:
+            cols[: int(rng.integers(10, ncol))] = "-"
+        s = list(cols)
+        for _ in range(int(rng.integers(0, 3))):
+            s.insert(int(rng.integers(0, len(s) + 1)), rng.choice(list("acgt")))
+        out.append("".join(s))
+    out[3] = "acgt"            # no columns
+    out[5] = out[5][:-2]       # wrong number of columns
+    return out
+
+
+def padded(text):
+    return np.concatenate([text, np.zeros(-len(text) % 16, dtype=np.uint8)])
+
+
+def test_encode_dev_equals_host_entry():
+    rng = np.random.default_rng(1)
+    ncol = 150
+    L = 5 * ncol
+    strings = amplicon_strings(rng, ncol, 333)
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    W = _lib.lib().stag_words_per_row(L)
+    bits = np.zeros((n, W), dtype=np.uint32)
+    n_char, n_al, status = (np.zeros(n, dtype=np.int32) for _ in range(3))
+    _lib.check(_lib.lib().stag_encode_a2m(0, L, _lib.ptr(text), _lib.ptr(offs), n, 35.0, _lib.ptr(bits), _lib.ptr(n_char),
+                                          _lib.ptr(n_al), _lib.ptr(status)))
+    t16 = padded(text)
+    d_text, d_offs = DevArray(t16), DevArray(offs)
+    d_bits = DevArray(shape=(n, W), dtype=np.uint32)
+    d_char, d_al, d_st = (DevArray(shape=(n,), dtype=np.int32) for _ in range(3))
+    _lib.check(_lib.lib().stag_encode_a2m_dev(L, d_text.ptr, len(t16), d_offs.ptr, n, 35.0, d_bits.ptr, d_char.ptr,
+                                              d_al.ptr, d_st.ptr, None))
+    assert np.array_equal(d_bits.get(), bits)
+    assert np.array_equal(d_char.get(), n_char) and np.array_equal(d_al.get(), n_al) and np.array_equal(d_st.get(), status)
+    assert len(set(status.tolist())) >= 3
+    # a text buffer that is not a multiple of 16 bytes is refused, not read past its end
+    if len(text) % 16:
+        assert _lib.lib().stag_encode_a2m_dev(L, d_text.ptr, len(text), d_offs.ptr, n, 0.0, d_bits.ptr, d_char.ptr, d_al.ptr,
+                                              d_st.ptr, None) != 0
+
+
+def test_classify_bits_dev_and_a2m_dev_equal_host_entries():
+    rng = np.random.default_rng(2)
+    ncol = 150
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[4], [1, 2, 5], [0, 2, 3]], 0.08)
+    strings = amplicon_strings(rng, ncol, 500)
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        ref = db.classify_a2m(strings, min_perc_state=20.0, want_bits=True)
+        D, K = db.max_depth, db.n_keys
+        # fused: text -> results
+        t16 = padded(text)
+        d_text, d_offs = DevArray(t16), DevArray(offs)
+        arrs, res = device_results(n, D, K)
+        db.reserve(n, len(t16))
+        _lib.check(_lib.lib().stag_classify_a2m_dev(db.handle, d_text.ptr, len(t16), d_offs.ptr, n, 20.0,
+                                                    ctypes.byref(res), None))
+        same_as_host(arrs, ref, n)
+        # rows -> results, with encode's status passed along (the statuses the walk itself gave --
+        # a node without classifier -- are for it to find again)
+        from_encode = np.isin(ref.status, (_lib.SEQ_ZERO_COLUMNS, _lib.SEQ_FILTERED, _lib.SEQ_LENGTH_MISMATCH))
+        assert from_encode.sum() >= 3 and (~from_encode & (ref.status != 0)).sum() >= 3
+        d_bits, d_st = DevArray(ref.bits), DevArray(np.where(from_encode, ref.status, 0).astype(np.int32))
+        arrs2, res2 = device_results(n, D, K)
+        _lib.check(_lib.lib().stag_classify_bits_dev(db.handle, d_bits.ptr, n, d_st.ptr, ctypes.byref(res2), None))
+        same_as_host(arrs2, ref, n, rows=~from_encode)      # n_aligned of a skipped row is recounted from its bits
+        assert np.array_equal(arrs2["status"].get(), ref.status)
+        assert (arrs2["path_len"].get()[from_encode] == 0).all()
+        # outputs the caller does not want may be NULL (status excepted)
+        arrs3, res3 = device_results(n, D, K)
+        res3.path_prob = None
+        res3.level_prob = None
+        _lib.check(_lib.lib().stag_classify_a2m_dev(db.handle, d_text.ptr, len(t16), d_offs.ptr, n, 20.0,
+                                                    ctypes.byref(res3), None))
+        assert np.array_equal(arrs3["path_node"].get(), ref.path_node)
+        assert np.array_equal(arrs3["selected"].get(), ref.selected)
+        assert not arrs3["path_prob"].get().any()
+
+
+def test_classify_protein_a2m_dev_equals_host_entry(capfd):
+    rng = np.random.default_rng(3)
+    naa = 30
+    L = 5 * 3 * naa
+    taxonomy, tax_function, classifiers = random_db(rng, 3 * naa, [[3], [2, 3, 3]], 0.1)
+    prots, genes = [], []
+    for i in range(200):
+        prot = "".join(rng.choice(list("ACDEFGHIKL-"), size=naa, p=[0.08] * 10 + [0.2]))
+        glen = 3 * sum(ch != "-" for ch in prot) + (3 if i % 2 else 0) + (1 if i % 19 == 0 else 0)
+        prots.append(prot)
+        genes.append("".join(rng.choice(list("ACGT"), size=glen)))
+    pt, po = tables.pack_text(prots)
+    gt, go = tables.pack_text(genes)
+    n = len(prots)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        ref = db.classify_protein_a2m_text(pt, po, gt, go, min_perc_state=10.0)
+        p16, g16 = padded(pt), padded(gt)
+        d = [DevArray(a) for a in (p16, po, g16, go)]
+        arrs, res = device_results(n, db.max_depth, db.n_keys)
+        _lib.check(_lib.lib().stag_classify_protein_a2m_dev(db.handle, d[0].ptr, len(p16), d[1].ptr, d[2].ptr, d[3].ptr, n,
+                                                            10.0, ctypes.byref(res), None))
+        same_as_host(arrs, ref, n)
+        assert (ref.status == _lib.SEQ_BACKTRANSLATE).sum() >= 5
+    capfd.readouterr()
+
+
+def test_classify_a2m_dev_under_stream_capture():
+    """One call recorded into a HIP graph, then replayed twice on fresh outputs."""
+    H = hip()
+    vp = ctypes.c_void_p
+    H.hipStreamCreate.argtypes = [ctypes.POINTER(vp)]
+    H.hipStreamBeginCapture.argtypes = [vp, ctypes.c_int]
+    H.hipStreamEndCapture.argtypes = [vp, ctypes.POINTER(vp)]
+    H.hipGraphInstantiate.argtypes = [ctypes.POINTER(vp), vp, vp, vp, ctypes.c_size_t]
+    H.hipGraphLaunch.argtypes = [vp, vp]
+    H.hipStreamSynchronize.argtypes = [vp]
+    H.hipGraphExecDestroy.argtypes = [vp]
+    H.hipGraphDestroy.argtypes = [vp]
+    H.hipStreamDestroy.argtypes = [vp]
+
+    rng = np.random.default_rng(4)
+    ncol = 200
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[5], [2, 4], [1, 3]], 0.05)
+    strings = amplicon_strings(rng, ncol, 2000)
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    t16 = padded(text)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        ref = db.classify_a2m(strings)
+        d_text, d_offs = DevArray(t16), DevArray(offs)
+        arrs, res = device_results(n, db.max_depth, db.n_keys)
+        db.reserve(n, len(t16))     # no allocation may happen while the stream is being captured
+        st, graph, gexec = vp(), vp(), vp()
+        assert H.hipStreamCreate(ctypes.byref(st)) == 0
+        try:
+            assert H.hipStreamBeginCapture(st, 0) == 0
+            rc = _lib.lib().stag_classify_a2m_dev(db.handle, d_text.ptr, len(t16), d_offs.ptr, n, 0.0, ctypes.byref(res), st)
+            assert H.hipStreamEndCapture(st, ctypes.byref(graph)) == 0
+            _lib.check(rc)
+            assert graph.value
+            assert H.hipGraphInstantiate(ctypes.byref(gexec), graph, None, None, 0) == 0
+            assert not arrs["path_len"].get().any()          # capture recorded the work, it did not run it
+            for _ in range(2):
+                for a in arrs.values():
+                    assert H.hipMemset(a.ptr, 0, max(a.nbytes, 16)) == 0
+                assert H.hipGraphLaunch(gexec, st) == 0
+                assert H.hipStreamSynchronize(st) == 0
+                same_as_host(arrs, ref, n)
+        finally:
+            if gexec.value:
+                H.hipGraphExecDestroy(gexec)
+            if graph.value:
+                H.hipGraphDestroy(graph)
+            H.hipStreamDestroy(st)
