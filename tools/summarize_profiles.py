@@ -23,8 +23,13 @@ def short(name):
     return name.split("<")[0]
 
 
+def newest(pattern):
+    """gpurun merges every run's files into the same directories: take the latest."""
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
 def counter(dirname, cname):
-    f = glob.glob(os.path.join(SRC, dirname, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(SRC, dirname, "*", "*_counter_collection.csv"))
     tot, disp = collections.Counter(), collections.defaultdict(set)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != cname:
@@ -36,7 +41,7 @@ def counter(dirname, cname):
 
 
 shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench_final.json"))
-stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
 
 fetch, nf = counter("pmc_fetch", "FETCH_SIZE")
