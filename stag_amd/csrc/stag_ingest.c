@@ -58,10 +58,10 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
             }
             const int64_t e = rstrip_end(buf, pos, line_end, &fb);
             unsigned char hi = 0;   /* a non-ASCII character is ONE column for the reference, not one per byte */
-            for (int64_t i = pos; i < e; ++i) {
+            memcpy(text_out + used, buf + pos, (size_t)(e - pos));
+            for (int64_t i = pos; i < e; ++i) {   /* vectorised by the compiler */
                 const unsigned char c = (unsigned char)buf[i];
-                text_out[used + (i - pos)] = (char)c;
-                hi |= c | (unsigned char)(c == '\r' ? 0x80 : 0);
+                hi |= (unsigned char)(c | (c == '\r' ? 0x80 : 0));
             }
             if (hi & 0x80) fb = 1;   /* also an inner '\r': a line break for text-mode readers */
             used += e - pos;
