@@ -48,7 +48,7 @@ def main():
     ap.add_argument("--reads", type=int, default=1_000_000, help="reads per GPU per step")
     ap.add_argument("--db-scale", type=float, default=1.0, help="scales the node count of the synthetic tree")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=300, help="reads timed through the NumPy port")
+    ap.add_argument("--cpu-sample", type=int, default=1500, help="reads timed through the NumPy port")
     ap.add_argument("--check", type=int, default=2000, help="reads compared with the C oracle after the run")
     args = ap.parse_args()
     if args.reads == 1_000_000 and args.db_scale == 1.0:
@@ -231,7 +231,7 @@ def main():
         from concurrent.futures import ThreadPoolExecutor
         from oracle import oracle_c
         threads = max(1, min(16, os.cpu_count() or 1))
-        per = 1500
+        per = 10000
         strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(min(n, threads * per))]
 
         def work(k):
