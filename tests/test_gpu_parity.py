@@ -450,3 +450,50 @@ def test_classify_concat_equals_host_concatenation():
         bad[3, 0] = len(dense[0])
         with pytest.raises(_lib.StagError):
             db.classify_concat(gene_len, gene_rows, bad)
+
+
+def caterpillar_db(rng, ncol, depth):
+    """A tree `depth` levels deep with few nodes: every level has 2-3 children, only the first goes on."""
+    L = 5 * ncol
+    taxonomy, classifiers = {"tree_root": []}, {}
+    parent, nid = "tree_root", 0
+    for d in range(depth):
+        k = 1 if d % 7 == 3 else int(rng.integers(2, 4))
+        kids = []
+        for _ in range(k):
+            nid += 1
+            kids.append("n%d" % nid)
+        taxonomy[parent] = kids
+        for kid in kids:
+            taxonomy[kid] = []
+            if k == 1:
+                classifiers[kid] = "no_negative_examples"
+            else:
+                w = rng.normal(0, 1, size=1 + L) * (rng.random(1 + L) < 0.1)
+                w[0] = rng.normal(0, 1) + (5.0 if kid == kids[0] else -2.0)   # most sequences go on down the spine
+                classifiers[kid] = w
+        parent = kids[0]
+    tax_function = {str(l): rng.normal(0, 1, size=1 + depth) for l in range(-1, depth)}
+    return taxonomy, tax_function, classifiers
+
+
+def test_deep_tree_up_to_the_rank_cut_tile_limit():
+    """31 levels with 32 rank-cut keys is what the rank-cut kernel's LDS tile holds (DESIGN.md, Limits);
+    one level more is refused with an error, not computed wrongly."""
+    rng = np.random.default_rng(31)
+    ncol, n = 40, 700
+    L = 5 * ncol
+    X = np.zeros((n, L), dtype=bool)
+    X[np.arange(n)[:, None], 5 * np.arange(ncol)[None, :] + rng.integers(0, 5, size=(n, ncol))] = True
+    taxonomy, tax_function, classifiers = caterpillar_db(rng, ncol, 31)
+    odb = oracle_c.DenseDB(taxonomy, tax_function, classifiers, L)
+    out = odb.classify(X)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        assert db.max_depth == 31 and db.n_keys == 32
+        res = db.classify_onehot(X)
+        assert (res.path_len == 31).sum() > 20 and len(set(res.path_len.tolist())) > 3
+        compare_with_oracle(db, odb, res, out, X, classifiers)
+    taxonomy, tax_function, classifiers = caterpillar_db(rng, ncol, 32)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        with pytest.raises(_lib.StagError, match="rank-cut"):
+            db.classify_onehot(X)
