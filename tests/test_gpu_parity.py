@@ -497,3 +497,25 @@ def test_deep_tree_up_to_the_rank_cut_tile_limit():
     with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
         with pytest.raises(_lib.StagError, match="rank-cut"):
             db.classify_onehot(X)
+
+
+def test_encode_at_the_row_width_limit():
+    """The encode kernel keeps one row per record in LDS: 65,000 columns (L = 325,000) still fit the
+    160 KB, 70,000 do not and are refused (Limits)."""
+    rng = np.random.default_rng(65)
+    ncol = 65000
+    strings = []
+    for _ in range(6):
+        s = np.full(ncol, "-", dtype="<U1")
+        a = int(rng.integers(0, ncol - 5000))
+        s[a:a + 5000] = rng.choice(list("ACGTUN"), size=5000)
+        strings.append("".join(s))
+    strings[2] = strings[2][:100] + "acgt" + strings[2][100:]
+    bits, n_char, n_al, status = encode_raw(strings, 5 * ncol)
+    dense = tables.unpack_rows(bits, bits.shape[1] * 32)
+    for i, s in enumerate(strings):
+        exp, e_char, e_al = oracle_c.encode_a2m(s)
+        assert n_char[i] == e_char == ncol and n_al[i] == e_al and status[i] == _lib.SEQ_OK
+        assert np.array_equal(dense[i, :5 * ncol], exp)
+    with pytest.raises(_lib.StagError, match="too large"):
+        encode_raw(["ACGT"], 5 * 70000)
