@@ -201,3 +201,43 @@ def test_classify_a2m_dev_under_stream_capture():
             if graph.value:
                 H.hipGraphDestroy(graph)
             H.hipStreamDestroy(st)
+
+
+def test_two_handles_on_two_streams_are_independent():
+    """Two handles of the same database, each with its own stream and batch, enqueued back to back
+    without a synchronisation in between: same results as one after the other."""
+    H = hip()
+    vp = ctypes.c_void_p
+    H.hipStreamCreate.argtypes = [ctypes.POINTER(vp)]
+    H.hipStreamSynchronize.argtypes = [vp]
+    H.hipStreamDestroy.argtypes = [vp]
+    rng = np.random.default_rng(6)
+    ncol = 180
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[4], [2, 3], [1, 2, 4]], 0.06)
+    batches = [amplicon_strings(rng, ncol, 3000), amplicon_strings(rng, ncol, 1700)]
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db_a, \
+            Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db_b:
+        refs = [db_a.classify_a2m(b) for b in batches]
+        streams, work = [], []
+        try:
+            for db, strings in zip((db_a, db_b), batches):
+                text, offs = tables.pack_text(strings)
+                t16 = padded(text)
+                st = vp()
+                assert H.hipStreamCreate(ctypes.byref(st)) == 0
+                streams.append(st)
+                arrs, res = device_results(len(strings), db.max_depth, db.n_keys)
+                db.reserve(len(strings), len(t16))
+                work.append((db, DevArray(t16), len(t16), DevArray(offs), len(strings), arrs, res, st))
+            for _ in range(3):      # several rounds in flight on both streams
+                for db, d_text, tb, d_offs, n, arrs, res, st in work:
+                    _lib.check(_lib.lib().stag_classify_a2m_dev(db.handle, d_text.ptr, tb, d_offs.ptr, n, 0.0,
+                                                                ctypes.byref(res), st))
+            for st in streams:
+                assert H.hipStreamSynchronize(st) == 0
+            for (db, d_text, tb, d_offs, n, arrs, res, st), ref in zip(work, refs):
+                same_as_host(arrs, ref, n)
+        finally:
+            for st in streams:
+                H.hipStreamDestroy(st)
