@@ -835,94 +835,139 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     double best_p = -1.0;
     int best_c = -1;
     const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
-    for (int pass0 = 0; pass0 < k; pass0 += NW) {
-        const bool active = pass0 + wave < k;
-        const int c = c0 + pass0 + wave;
-        const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
-        double z = 0.0;
-        if (active) {   // two 8-byte gathers per lane; lanes of one task mostly share the addresses
-            const size_t base = (size_t)c * (a.NC + 1);
-            int i_lo = own_lo, i_hi = own_hi;
-            asm volatile("" : "+v"(i_lo), "+v"(i_hi));   // keeps the two 64-bit addresses out of long-lived registers
-            z = a.gappre[base + i_lo] + a.gapsuf[base + i_hi];
-        }
-        for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
-            const int sB = min(wB, sA + WCAP_CHUNKS);
-            // this wave's coefficient range of the slice: contiguous, chunk after chunk
-            uint32_t e_lo = 0, e_hi = 0;
-            if (active) { e_lo = bo[sA] * BLOCK_ENTRIES; e_hi = bo[sB] * BLOCK_ENTRIES; }
-            uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-            if (lane < ENT_PIECE && e_lo + lane < e_hi) ent = a.blocks[e_lo + lane];   // in flight together with the rows
-            if (!one_slice || pass0 == 0) {
-                const int w0 = sA * CHUNK_WORDS;
-                const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
-                uint32_t v[TILE / NW];
+    // rows of the slice [sA, sB) -> LDS: one row per wave and step, lanes over words.  Ends with the
+    // stores issued; the caller's barrier makes them visible.
+    auto stage_rows = [&](int sA, int sB) {
+        const int w0 = sA * CHUNK_WORDS;
+        const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
+        uint32_t v[TILE / NW];
 #pragma unroll
-                for (int rr = 0; rr < TILE / NW; ++rr) {   // one row per wave and step, lanes over words
-                    // the row's sequence id as a scalar: its address is then computed once per wave
-                    const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-                    v[rr] = 0u;
-                    if (s >= 0) {
-                        const uint32_t *src = a.bits + ((size_t)s * a.W + w0);
-                        if (lane < width) v[rr] = src[lane];
-                    }
-                }
-                __syncthreads();  // everyone is done reading the previous slice
-#pragma unroll
-                for (int rr = 0; rr < TILE / NW; ++rr) s_rows[(rr * NW + wave) * ROW_STRIDE + lane] = v[rr];
-                if (lane < ENT_PIECE) s_ent[lane] = ent;
-                __syncthreads();
-            } else {
-                if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private: LDS operations of one wave stay in order
+        for (int rr = 0; rr < TILE / NW; ++rr) {
+            // the row's sequence id as a scalar: its address is then computed once per wave
+            const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+            v[rr] = 0u;
+            if (s >= 0) {
+                const uint32_t *src = a.bits + ((size_t)s * a.W + w0);
+                if (lane < width) v[rr] = src[lane];
             }
-            // which chunks of this slice lie in the lane's own window (bit i: chunk sA + i)
-            const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
-                                      ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
-            if (active) {
-                // entry offsets are relative to the row; the slice starts at chunk sA
-                const char *my_row = reinterpret_cast<const char *>(s_rows) +
-                                     (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-                if (e_hi - e_lo <= (uint32_t)ENT_PIECE) {
-                    // the usual case: every coefficient of the slice is in s_ent
-                    for (int ch = sA; ch < sB; ++ch) {
-                        const uint32_t e0 = bo[ch] * BLOCK_ENTRIES - e_lo, e1 = bo[ch + 1] * BLOCK_ENTRIES - e_lo;
-                        double cs = 0.0;
-                        for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                            const uint4 *pe = &s_ent[e];   // wave-uniform address: LDS broadcast
-                            const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
-                            cs += masked_weight_v(my_row, n0);
-                            cs += masked_weight_v(my_row, n1);
-                            cs += masked_weight_v(my_row, n2);
-                            cs += masked_weight_v(my_row, n3);
-                        }
-                        z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
+        }
+        __syncthreads();  // everyone is done reading the previous slice
+#pragma unroll
+        for (int rr = 0; rr < TILE / NW; ++rr) s_rows[(rr * NW + wave) * ROW_STRIDE + lane] = v[rr];
+    };
+    auto fetch_ent = [&](uint32_t e_lo, uint32_t e_hi) {
+        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
+        if (lane < ENT_PIECE && e_lo + lane < e_hi) ent = a.blocks[e_lo + lane];
+        return ent;
+    };
+    // z += the sibling's chunk sums over the slice [sA, sB) (its first ENT_PIECE coefficients are in s_ent)
+    auto score_slice = [&](double &z, const uint32_t STAG_CONST *bo, uint32_t e_lo, uint32_t e_hi, int sA, int sB) {
+        // which chunks of this slice lie in the lane's own window (bit i: chunk sA + i)
+        const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
+                                  ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
+        // entry offsets are relative to the row; the slice starts at chunk sA
+        const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
+        if (e_hi - e_lo <= (uint32_t)ENT_PIECE) {
+            // the usual case: every coefficient of the slice is in s_ent
+            for (int ch = sA; ch < sB; ++ch) {
+                const uint32_t e0 = bo[ch] * BLOCK_ENTRIES - e_lo, e1 = bo[ch + 1] * BLOCK_ENTRIES - e_lo;
+                double cs = 0.0;
+                for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                    const uint4 *pe = &s_ent[e];   // wave-uniform address: LDS broadcast
+                    const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                    cs += masked_weight_v(my_row, n0);
+                    cs += masked_weight_v(my_row, n1);
+                    cs += masked_weight_v(my_row, n2);
+                    cs += masked_weight_v(my_row, n3);
+                }
+                z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
+            }
+        } else {
+            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
+            for (int ch = sA; ch < sB; ++ch) {
+                const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
+                double cs = 0.0;
+                for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
+                    if (e >= piece + ENT_PIECE) {   // more than 48 coefficients in the slice: next piece
+                        piece = e;
+                        if (lane < ENT_PIECE)
+                            s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
                     }
+                    const uint4 *pe = &s_ent[e - piece];
+                    const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                    cs += masked_weight_v(my_row, n0);
+                    cs += masked_weight_v(my_row, n1);
+                    cs += masked_weight_v(my_row, n2);
+                    cs += masked_weight_v(my_row, n3);
+                }
+                z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
+            }
+        }
+    };
+    auto gap_consts = [&](int c) {   // two 8-byte gathers per lane; lanes of one task mostly share the addresses
+        const size_t base = (size_t)c * (a.NC + 1);
+        int i_lo = own_lo, i_hi = own_hi;
+        asm volatile("" : "+v"(i_lo), "+v"(i_hi));   // keeps the two 64-bit addresses out of long-lived registers
+        return a.gappre[base + i_lo] + a.gapsuf[base + i_hi];
+    };
+    auto decide = [&](double z, int c) {
+        const double p = sigmoid(z + as_const(a.intercept)[c]);
+        if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
+    };
+
+    if (one_slice) {
+        // ---- the usual case: the window fits the staging buffer, staged once for all siblings
+        for (int pass0 = 0; pass0 < k; pass0 += NW) {
+            const bool active = pass0 + wave < k;
+            const int c = c0 + pass0 + wave;
+            const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
+            double z = 0.0;
+            if (active) z = gap_consts(c);
+            if (wB > wA) {
+                // this wave's coefficient range of the window: contiguous, chunk after chunk
+                uint32_t e_lo = 0, e_hi = 0;
+                if (active) { e_lo = bo[wA] * BLOCK_ENTRIES; e_hi = bo[wB] * BLOCK_ENTRIES; }
+                const uint4 ent = fetch_ent(e_lo, e_hi);   // in flight together with the rows
+                if (pass0 == 0) {
+                    stage_rows(wA, wB);
+                    if (lane < ENT_PIECE) s_ent[lane] = ent;
+                    __syncthreads();
                 } else {
-                    uint32_t piece = e_lo;   // first entry held in s_ent[wave]
-                    for (int ch = sA; ch < sB; ++ch) {
-                        const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
-                        double cs = 0.0;
-                        for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                            if (e >= piece + ENT_PIECE) {   // more than 48 coefficients in the slice: next piece
-                                piece = e;
-                                if (lane < ENT_PIECE)
-                                    s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
-                            }
-                            const uint4 *pe = &s_ent[e - piece];
-                            const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
-                            cs += masked_weight_v(my_row, n0);
-                            cs += masked_weight_v(my_row, n1);
-                            cs += masked_weight_v(my_row, n2);
-                            cs += masked_weight_v(my_row, n3);
-                        }
-                        z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
+                    if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private: LDS operations of one wave stay in order
+                }
+                if (active) score_slice(z, bo, e_lo, e_hi, wA, wB);
+            }
+            if (active) decide(z, c);
+        }
+    } else {
+        // ---- a window wider than the staging buffer: slice after slice; each slice is staged once for
+        // two passes (8 siblings), whose sums wait in registers
+        constexpr int PG = 2;   // 4 measured slower: the sums then spill
+        for (int pg0 = 0; pg0 < k; pg0 += PG * NW) {
+            double zz[PG];
+#pragma unroll
+            for (int j = 0; j < PG; ++j) {
+                zz[j] = 0.0;
+                if (pg0 + j * NW + wave < k) zz[j] = gap_consts(c0 + pg0 + j * NW + wave);
+            }
+            for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
+                const int sB = min(wB, sA + WCAP_CHUNKS);
+                stage_rows(sA, sB);
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < PG; ++j) {
+                    if (pg0 + j * NW + wave < k) {   // wave-uniform
+                        const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
+                        const uint32_t e_lo = bo[sA] * BLOCK_ENTRIES, e_hi = bo[sB] * BLOCK_ENTRIES;
+                        const uint4 ent = fetch_ent(e_lo, e_hi);
+                        if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private, after the previous sibling's reads
+                        score_slice(zz[j], bo, e_lo, e_hi, sA, sB);
                     }
                 }
             }
-        }
-        if (active) {
-            const double p = sigmoid(z + as_const(a.intercept)[c]);
-            if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
+#pragma unroll
+            for (int j = 0; j < PG; ++j)
+                if (pg0 + j * NW + wave < k) decide(zz[j], c0 + pg0 + j * NW + wave);
         }
     }
     s_z(wave)[lane] = best_p;
