@@ -64,8 +64,6 @@ struct __attribute__((aligned(16))) LevelRec {
     double prob;        // 2.0 = "single child" placeholder (classify.py:37)
 };
 // plain vector types: unlike HIP's uint4 class they can be loaded from the constant address space
-using u32x4 = __attribute__((ext_vector_type(4))) uint32_t;
-using i32x4 = __attribute__((ext_vector_type(4))) int32_t;
 using i32x8 = __attribute__((ext_vector_type(8))) int32_t;
 
 // ------------------------------------------------------------------------------------------
@@ -717,13 +715,6 @@ struct WalkArgs {
 };
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
-
-// e = {off, bit, w_lo, w_hi} in SGPRs; returns w if this lane's row has the feature, else +0.0
-__device__ __forceinline__ double masked_weight(const char *my_row, const u32x4 e) {
-    const uint32_t x = *reinterpret_cast<const uint32_t *>(my_row + e.x);
-    const int m = __builtin_amdgcn_sbfe((int)x, e.y, 1u);  // 0 or -1
-    return __hiloint2double((int)e.w & m, (int)e.z & m);
-}
 
 // 64-lane min / max with DPP moves (no LDS traffic); the result is wave-uniform.
 __device__ __forceinline__ int wave_min_i(int v) {
