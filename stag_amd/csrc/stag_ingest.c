@@ -47,7 +47,12 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
             }
             fb = 0;
             const int64_t e = rstrip_end(buf, pos, line_end, &fb);
-            if (memchr(buf + pos, '\r', (size_t)(e - pos))) fb = 1;   /* a line break for text-mode readers */
+            {   /* a '\r' is a line break for text-mode readers: anywhere but right at the end of the line it
+                 * starts another line there (which counts even when it is blank after stripping) */
+                int64_t lim = line_end;
+                if (lim > pos && buf[lim - 1] == '\r') --lim;
+                if (memchr(buf + pos, '\r', (size_t)(lim - pos))) fb = 1;
+            }
             open = 1;
             r_begin = pos; r_id = pos + 1; r_idlen = e - (pos + 1); r_lines = 0; r_text = used;
         } else {

@@ -83,7 +83,8 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
     (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1); with
     text_mode, as read_fasta(open(path), is_binary=False): universal newlines, so a lone '\r' also
-    ends a line (the gene file of align.py:150)."""
+    ends a line (the gene file of align.py:150).  batch_records is a target, not a bound: records
+    that had to be re-parsed the slow way are all added to the batch that was being filled."""
     L = lib()
     buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
     scratch = np.empty(len(buf), dtype=np.uint8)
@@ -134,9 +135,8 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
             elif n:
                 begins = (recs["id_begin"] + (pos - 1 + head_start)).tolist()
                 ends = (recs["id_begin"] + recs["id_len"] + pos).tolist()
-                ids.extend([bytes(buf[b:e]).decode("utf-8") for b, e in zip(begins, ends)])
-                if recs["id_len"][0] < 0:          # lines before the first header: sid is None
-                    ids[len(ids) - n] = None
+                # (lines before the first header form a record without id: sid is None, id_len < 0)
+                ids.extend([bytes(buf[b:e]).decode("utf-8") if e >= b else None for b, e in zip(begins, ends)])
                 texts.append(scratch[:used.value].copy())
                 offs_parts.append(offs[1:n + 1] + total)
                 total += used.value
@@ -145,8 +145,8 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
             pos += consumed.value
             if len(ids) >= batch_records:
                 yield flush()
-                continue          # more records may be waiting in this buffer
-            break
+            if not consumed.value:
+                break             # the rest of the buffer is an incomplete record (or nothing)
         # keep the unparsed tail; a record longer than the buffer makes the buffer grow
         rest = have - pos
         if pos == 0 and have == len(buf) and not ended:

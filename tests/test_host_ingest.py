@@ -135,3 +135,35 @@ def test_bad_arguments_are_rejected():
     c = ctypes.c_int64(0)
     assert L.stag_onehot_parse(None, 0, 1, 5, 4, 1, None, None, ctypes.byref(c)) == -1
     assert L.stag_fasta_scan(None, 0, 1, 1, 1, None, 0, 0, None, None, ctypes.byref(c), ctypes.byref(c)) == -1
+
+
+def test_fasta_scan_random_streams_equal_the_python_reader():
+    """Seeded random byte streams (headers, wrapped lines, blank lines, '\\r', tabs, non-ASCII bytes,
+    missing final newline) through the native scanner at random chunk and batch sizes against
+    stag_amd.helpers.read_fasta, the port of helpers.py:107-121 that the golden vectors pin."""
+    from stag_amd.helpers import read_fasta
+    rng = np.random.default_rng(2024)
+    pieces = [b">", b"\n", b"\n", b"\r\n", b"\r", b" ", b"\t", b"-", b"ACGT", b"acgu", b"N.", b"\xc3\xa9", b"\xc2\xa0",
+              b"\xc2\x85", b"id_1", b"---A--", b">seq two\n", b"\x1c", b"\x0b", b"\xe2\x80\xa8", b"\x0c", b">\n"]
+    for case in range(1500):
+        m = int(rng.integers(0, 60))
+        data = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), size=m))
+        if case % 3 == 0:
+            data = b">first\n" + data
+        for text_mode in (False, True):
+            if text_mode:
+                want = [[i, s] for i, s in read_fasta(io.TextIOWrapper(io.BytesIO(data), encoding="utf-8", newline=None),
+                                                      head_start=1, is_binary=False)]
+            else:
+                want = [[i, s] for i, s in read_fasta(io.BytesIO(data), head_start=1)]
+            chunk = int(rng.choice([1, 2, 5, 17, 4096]))
+            batch = int(rng.choice([1, 3, 1 << 16]))
+            # sequence text travels one byte per CHARACTER (a character is one column for the reference):
+            # a non-ASCII character becomes its latin-1 byte or '?', never an A/C/G/T/U
+            want = [[i, s.encode("latin-1", "replace")] for i, s in want]
+            got = []
+            for ids, text, offs in ingest.fasta_batches(io.BytesIO(data), batch_records=batch, chunk_bytes=chunk,
+                                                        text_mode=text_mode):
+                assert len(text) % 16 == 0      # (a re-parsed stretch may push a batch past batch_records)
+                got += [[sid, bytes(text[offs[i]:offs[i + 1]])] for i, sid in enumerate(ids)]
+            assert got == want, (case, text_mode, chunk, batch, data)
