@@ -167,3 +167,46 @@ def test_fasta_scan_random_streams_equal_the_python_reader():
                 assert len(text) % 16 == 0      # (a re-parsed stretch may push a batch past batch_records)
                 got += [[sid, bytes(text[offs[i]:offs[i + 1]])] for i, sid in enumerate(ids)]
             assert got == want, (case, text_mode, chunk, batch, data)
+
+
+def test_onehot_parse_random_files_equal_the_per_line_parser(tmp_path):
+    """Seeded random -s files (well-formed lines with occasional damage, and byte soup) through the
+    native parser at random chunk and batch sizes against parse_onehot_line over text-mode lines
+    (classify.py:16-20; pinned by the golden vectors): same ids, field counts, bits, and the same
+    exception class when a field is not an integer."""
+    rng = np.random.default_rng(4242)
+    pieces = [b"0", b"1", b"\t", b"\t", b"\t", b"\n", b"\n", b"\r\n", b"\r", b"id", b" ", b"2", b"-1", b"10", b"01",
+              b"\xc3\xa9", b"\xc2\xa0", b"x", b"\x0b", b"+1", b"1_0"]
+    path = tmp_path / "s.tsv"
+    for case in range(1200):
+        if case % 2 == 0:
+            lines, L0 = [], int(rng.integers(0, 8))
+            for r in range(int(rng.integers(0, 6))):
+                m = L0 if rng.random() < 0.8 else int(rng.integers(0, 8))
+                line = b"\t".join([b"g%d" % r] + [bytes(rng.choice([b"0", b"1"])) for _ in range(m)])
+                if rng.random() < 0.15:
+                    line += pieces[int(rng.integers(0, len(pieces)))]
+                lines.append(line + bytes(rng.choice([b"\n", b"\r\n", b"\r", b" \n"])))
+            data = b"".join(lines)
+            if rng.random() < 0.3 and data:
+                data = data[:-1]
+        else:
+            data = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), size=int(rng.integers(0, 30))))
+        path.write_bytes(data)
+        try:
+            with open(path, "r") as fh:
+                want = [(gid, [bool(v) for v in x]) for gid, x in map(parse_onehot_line, fh)]
+        except Exception as e:      # noqa: BLE001
+            want = type(e).__name__
+        for L in (0, 3, 5):
+            chunk, rows = int(rng.choice([1, 2, 7, 4096])), int(rng.choice([1, 2, 7, 100]))
+            try:
+                got = rows_of(str(path), L, chunk, batch_rows=rows)
+            except Exception as e:      # noqa: BLE001
+                got = type(e).__name__
+            if isinstance(want, str) or isinstance(got, str):
+                assert got == want, (case, L, chunk, rows, data)
+                continue
+            assert [g[0] for g in got] == [w[0] for w in want], (case, L, chunk, rows, data)
+            for g, w in zip(got, want):
+                assert g[1] == len(w[1]) and (g[2] is None or g[2] == [int(v) for v in w[1]]), (case, L, chunk, rows, data)
