@@ -44,6 +44,30 @@ def test_backtranslate_golden():
         assert got == case["result"], case
 
 
+def test_backtranslate_random_pairs_equal_the_oracle(capfd):
+    """Seeded random (protein alignment, gene) pairs, with inserts, odd symbols, stop codons and wrong
+    lengths, with and without the length check: the host entry point against the NumPy-free restatement
+    of align.py:63-94 that the golden vectors pin."""
+    from oracle import oracle_np
+    rng = np.random.default_rng(6394)
+    alphabet = list("ACDEFGHIKLMNPQRSTVWY") + ["-", "-", "-", "a", "c", "x", ".", "*", "X", "1"]
+    for case in range(3000):
+        m = int(rng.integers(0, 40))
+        prot = "".join(rng.choice(alphabet, size=m))
+        res = sum(ch != "-" for ch in prot)
+        glen = max(0, 3 * res + int(rng.choice([0, 0, 3, 3, 1, -1, 2, -3, 6])))
+        gene = "".join(rng.choice(list("ACGTNacgt-"), size=glen))
+        for check in (True, False):
+            want = oracle_np.protein2gene_alignment("g", prot, gene, check_length=check)
+            p, g = prot.encode(), gene.encode()
+            out = ctypes.create_string_buffer(3 * len(p) + 4)
+            n = ctypes.c_int64(0)
+            _lib.check(_lib.lib().stag_backtranslate(p, len(p), g, len(g), int(check), out, ctypes.byref(n)))
+            got = None if n.value < 0 else out.raw[:n.value].decode()
+            assert got == want, (prot, gene, check)
+    capfd.readouterr()
+
+
 def test_no_gpu_fails_loudly():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is visible")
