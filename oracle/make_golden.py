@@ -346,12 +346,15 @@ def gen_tsv():
 # ---------------------------------------------------------------- concat_alignments (a15)
 def gen_concat():
     rng = np.random.default_rng(41)
-    gene_order = ["COG0012", "COG0016", "COG0018"]
-    ali_lengths = {"COG0012": "10", "COG0016": "15", "COG0018": "5"}
+    gene_order = ["COG0012", "COG0016", "COG0018", "MG_4"]
+    ali_lengths = {"COG0012": "10", "COG0016": "15", "COG0018": "5", "MG_4": "5"}
     files = {
         "COG0012": ["dir/genomeA.fna_12##COG0012", "dir/genomeB.fna_7##COG0012", "plain.3##COG0012"],
         "COG0016": ["dir/genomeA.fna_40##COG0016", "solo##COG0016"],
         # COG0018 file does not exist
+        # a marker-gene name with '_': concat_alignments (classify_genome.py:372) picks the separator from the
+        # WHOLE id, merge_gene_predictions (:353) from the part before '##' -- they disagree on "plain.3"
+        "MG_4": ["plain.3##MG_4", "dotted.name.9##MG_4", "dir/genomeA.fna_12##MG_4", "solo##MG_4"],
     }
     with tempfile.TemporaryDirectory() as tmp:
         stored = {}
@@ -367,8 +370,18 @@ def gen_concat():
             path = ref_genome.concat_alignments(None, tmp, gene_order, ali_lengths)
         text = open(path).read()
         os.remove(path)
+    # merge_gene_predictions (classify_genome.py:343-362) on ids of the same kinds
+    preds = {"dir/genomeA.fna_12##COG0012": "Bacteria;Firmicutes", "dir/genomeA.fna_40##COG0016": "Bacteria",
+             "plain.3##COG0012": "", "plain.3##MG_4": "Archaea", "dotted.name.9##MG_4": "Bacteria;X",
+             "solo##MG_4": "Bacteria"}
+    with tempfile.TemporaryDirectory() as tmp:
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_genome.merge_gene_predictions(None, [], preds, 1, 1, tmp, False, False)
+        merged = {name: open(os.path.join(tmp, "genes_predictions", name)).read()
+                  for name in sorted(os.listdir(os.path.join(tmp, "genes_predictions")))}
     dump("concat.json", {"gene_order": gene_order, "ali_lengths": ali_lengths,
-                         "ali_files": stored, "concatenated": text})
+                         "ali_files": stored, "concatenated": text,
+                         "predictions": preds, "merged_files": merged})
 
 
 # ---------------------------------------------------------------- stagDB written by the reference writer

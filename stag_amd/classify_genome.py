@@ -54,10 +54,20 @@ def annotate_MGs(MGS, database_files, database_base_path, dir_ali, procs=2, pack
 
 
 def _genome_of(seq_id):
-    """classify_genome.py:352-355 / :372-374: id before '##', last '_' (or '.') token dropped."""
+    """classify_genome.py:352-355 (merge_gene_predictions): the part before '##' with its last '_'
+    (or '.', when it has no '_') token dropped."""
     genome = seq_id.split("##")[0]
     sep = "_" if "_" in genome else "."
     toks = genome.split(sep)
+    return sep.join(toks[:-1] if len(toks) > 1 else toks)
+
+
+def _genome_of_ali_id(seq_id):
+    """classify_genome.py:372-374 (concat_alignments): as above, but the separator is chosen from the
+    WHOLE id, marker-gene name included -- "plain.3##MG_4" stays "plain.3" there while
+    merge_gene_predictions files it under "plain".  Kept as the reference has it."""
+    sep = "_" if "_" in seq_id else "."
+    toks = seq_id.split("##")[0].split(sep)
     return sep.join(toks[:-1] if len(toks) > 1 else toks)
 
 
@@ -86,7 +96,7 @@ def concat_alignments(genome_files, ali_dir, gene_order, ali_lengths, full_genom
             with open(mg_alignment_file) as align_in:
                 for line in align_in:
                     genome, *alignment = line.strip().split("\t")
-                    genome = _genome_of(genome)
+                    genome = _genome_of_ali_id(genome)
                     if genome not in all_genes:
                         all_genes[genome] = ["\t".join(["0"] * int(ali_lengths[g])) for g in gene_order]
                     all_genes[genome][pos] = "\t".join(alignment)
@@ -118,7 +128,7 @@ def concat_on_device(packed, gene_order, ali_lengths):
         r = 0
         for ids, _ in batches:
             for seq_id in ids:
-                genome = _genome_of(seq_id)
+                genome = _genome_of_ali_id(seq_id)
                 j = genomes.setdefault(genome, len(genomes))
                 if j == len(src):
                     src.append([-1] * len(gene_order))

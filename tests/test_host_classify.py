@@ -301,13 +301,12 @@ def test_concat_and_merge_match_reference(tmp_path):
     path = scg.concat_alignments(None, str(ali), g["gene_order"], g["ali_lengths"])
     assert open(path).read() == g["concatenated"]
     os.remove(path)
-    preds = {"dir/genomeA.fna_12##COG0012": "Bacteria;Firmicutes", "dir/genomeA.fna_40##COG0016": "Bacteria",
-             "plain.3##COG0012": ""}
-    scg.merge_gene_predictions(None, [], preds, 1, 1, str(tmp_path), False, False)
-    got = (tmp_path / "genes_predictions" / "genomeA.fna").read_text().splitlines()
-    assert got == ["dir/genomeA.fna_12##COG0012\tCOG0012\tBacteria;Firmicutes",
-                   "dir/genomeA.fna_40##COG0016\tCOG0016\tBacteria"]
-    assert (tmp_path / "genes_predictions" / "plain").read_text() == "plain.3##COG0012\tCOG0012\t\n"
+    # the files merge_gene_predictions of the reference wrote for these predictions (names and contents)
+    scg.merge_gene_predictions(None, [], g["predictions"], 1, 1, str(tmp_path), False, False)
+    outdir = tmp_path / "genes_predictions"
+    assert {f.name: f.read_text() for f in outdir.iterdir()} == g["merged_files"]
+    # the two functions do not agree on the genome of "plain.3##MG_4" (classify_genome.py:353 vs :372)
+    assert "plain.3\t" in g["concatenated"] and "plain.3" not in g["merged_files"]
 
 
 WORKER = r'''
