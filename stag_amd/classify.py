@@ -132,7 +132,15 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                         res = db.classify_protein_a2m_text(text, offs, gene[0], gene[1], min_perc_state=min_perc_state,
                                                            want_bits=want_bits)
                     _report_backtranslation_failure(res.status, ids, text, offs, gene)
-                    raise_for_status(res.status, ids)
+                    failed = np.flatnonzero((res.status != _lib.SEQ_OK) & (res.status != _lib.SEQ_FILTERED))
+                    if failed.size:
+                        # the reference stops at the first failing sequence; by then it has written the -S
+                        # lines of the sequences before it (classify.py:158-162)
+                        before = np.flatnonzero(res.status[:failed[0]] == _lib.SEQ_OK)
+                        if save_ali_to_file and rank == 0 and len(before):
+                            alignment_out.write(ingest.format_onehot([ids[i] for i in before], res.bits[before],
+                                                                     db.n_features))
+                        raise_for_status(res.status, ids)
                     passed = np.flatnonzero(res.status == _lib.SEQ_OK)
                     n_pass += len(passed)
                     n_not_pass += len(ids) - len(passed)

@@ -163,9 +163,14 @@ def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_pa
     # a gene of the wrong length: message of align.py:70-73, then the reference's TypeError
     gene_file.write_text("".join(">r%d\n%s\n" % (i, s + ("A" if i == 4 else "")) for i, s in enumerate(genes)))
     capsys.readouterr()
+    saved = tmp_path / "partial.tsv"
     with pytest.raises(TypeError):
-        sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o2"))
+        sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o2"),
+                    save_ali_to_file=str(saved))
     assert "length of genes/alignment is not correct" in capsys.readouterr().err
+    # by then the reference has written the -S lines of the four sequences before it (classify.py:158-162)
+    want = [oracle_np.onehot_line("r%d" % i, oracle_np.convert_alignment(nucs[i])[0]) for i in range(4)]
+    assert saved.read_text() == "\n".join(want) + "\n"
     # identifiers that do not pair up: sys.exit(1) (align.py:152-154)
     gene_file.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(genes)))
     with pytest.raises(SystemExit):
