@@ -109,10 +109,14 @@ def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
         for pids, ptext, poffs in ingest.fasta_batches(parse_proc.stdout, batch_records=size):
             gids, gtext, goffs = next(genes, ([], None, None))
             m = min(len(pids), len(gids))          # zip() stops with the shorter stream (align.py:148)
-            for pid, gid in zip(pids[:m], gids[:m]):
-                if pid != gid:
-                    sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(pid, gid))
-                    sys.exit(1)
+            clash = next((j for j in range(m) if pids[j] != gids[j]), None)
+            if clash is not None:
+                # the reference gets this far only if the pairs before it went through (align.py:149-159):
+                # let them, then stop as it does
+                if clash:
+                    yield pids[:clash], ptext, poffs[:clash + 1], (gtext, goffs[:clash + 1])
+                sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(pids[clash], gids[clash]))
+                sys.exit(1)
             if m:
                 yield pids[:m], ptext, poffs[:m + 1], (gtext, goffs[:m + 1])
             if m < len(pids):

@@ -175,6 +175,11 @@ def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_pa
     gene_file.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(genes)))
     with pytest.raises(SystemExit):
         sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o3"))
+    # both in one stream: the reference fails at whichever comes first (pair 4 before pair 6)
+    gene_file.write_text("".join(">%s%d\n%s\n" % ("q" if i == 6 else "r", i, s + ("A" if i == 4 else ""))
+                                 for i, s in enumerate(genes)))
+    with pytest.raises(TypeError):
+        sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o4"))
 
 
 def test_classify_genome_fused_concat_equals_text_path(fake_gpu, monkeypatch, tmp_path):
