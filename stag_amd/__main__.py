@@ -45,23 +45,23 @@ def print_menu_classify_genome():
 
 def main(argv=None):
     parser = argparse.ArgumentParser(prog="stag", add_help=False)
-    parser.add_argument('command', action="store", default=None, choices=['classify', 'classify_genome'])
-    parser.add_argument('-o', action="store", dest='output', default=None)
-    parser.add_argument('-t', type=int, action="store", dest='threads', default=1)
-    parser.add_argument('-v', action='store', type=int, default=3, dest='verbose', choices=list(range(1, 5)))
-    parser.add_argument('-s', action="store", default=None, dest='aligned_sequences')
-    parser.add_argument('-f', action='store_true', dest='force_rewrite')
-    parser.add_argument('-i', action="store", dest='fasta_input', default=None)
-    parser.add_argument('-p', action="store", dest='protein_fasta_input', default=None)
-    parser.add_argument('-d', action="store", dest='database', default=None)
-    parser.add_argument('-S', action="store", dest='intermediate_al', default=None)
-    parser.add_argument('-m', action='store', type=int, default=None, dest='min_perc_state')
-    parser.add_argument('-l', action='store_true', dest='long_out')
-    parser.add_argument('-r', action='store_true', dest='keep_all_genes')
-    parser.add_argument('-D', action="store", dest='dir_input', default=None)
-    parser.add_argument('-G', action="store", dest="marker_genes", default=None)
-    parser.add_argument('--version', action='version',
-                        version='%(prog)s {0} on python {1}'.format(tool_version, sys.version.split()[0]))
+    parser.add_argument("command", choices=["classify", "classify_genome"])
+    # flag -> (attribute the reference's code reads, type or None for a switch): stag/__main__.py:205-236
+    flags = {
+        "-d": ("database", str), "-i": ("fasta_input", str), "-p": ("protein_fasta_input", str),
+        "-s": ("aligned_sequences", str), "-S": ("intermediate_al", str), "-o": ("output", str),
+        "-D": ("dir_input", str), "-G": ("marker_genes", str), "-m": ("min_perc_state", int),
+        "-l": ("long_out", None), "-f": ("force_rewrite", None), "-r": ("keep_all_genes", None),
+    }
+    for flag, (dest, kind) in flags.items():
+        if kind is None:
+            parser.add_argument(flag, dest=dest, action="store_true")
+        else:
+            parser.add_argument(flag, dest=dest, type=kind, default=None)
+    parser.add_argument("-t", dest="threads", type=int, default=1)
+    parser.add_argument("-v", dest="verbose", type=int, default=3, choices=[1, 2, 3, 4])
+    parser.add_argument("--version", action="version",
+                        version="%(prog)s {0} on python {1}".format(tool_version, sys.version.split()[0]))
     args = parser.parse_args(argv)
 
     if args.min_perc_state is None:

@@ -6,33 +6,32 @@ import sys
 
 
 def is_tool(name):
-    """helpers.py:68-75: True unless starting `name` fails with ENOENT."""
+    """helpers.py:68-75: a tool counts as present unless the attempt to start it says "no such file"."""
     try:
-        with open(os.devnull) as devnull:
-            subprocess.Popen([name], stdout=devnull, stderr=devnull).communicate()
+        subprocess.run([name], stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except FileNotFoundError:
+        return False
     except OSError as e:
-        if e.errno == errno.ENOENT:
-            return False
+        return e.errno != errno.ENOENT
     return True
 
 
 def read_fasta(fasta_stream, head_start=0, is_binary=True):
-    """helpers.py:107-121: streaming (id, sequence); lines are rstrip()ped and joined; a record
-    with an empty sequence is not yielded; head_start=1 drops the '>'."""
-    sid, seq = None, []
-    for line in fasta_stream:
-        if is_binary:
-            line = line.decode("utf-8")
-        line = line.rstrip()
-        if line.startswith(">"):
-            if seq:
-                yield sid, "".join(seq)
-            sid = line[head_start:]
-            seq.clear()
-        else:
-            seq.append(line)
-    if seq:
-        yield sid, "".join(seq)
+    """helpers.py:107-121 as a slow-path restatement (the fast path is stag_amd.ingest.fasta_batches):
+    every line right-stripped; a line starting with '>' closes the record before it; a record is
+    reported as (header[head_start:], its lines joined) only if it had at least one line; lines before
+    the first header form a record whose id is None."""
+    header, lines = None, []
+    for raw in fasta_stream:
+        text = (raw.decode("utf-8") if is_binary else raw).rstrip()
+        if text[:1] != ">":
+            lines.append(text)
+            continue
+        if lines:
+            yield header, "".join(lines)
+        header, lines = text[head_start:], []
+    if lines:
+        yield header, "".join(lines)
 
 
 def check_file_exists(file_name, isfasta=False):
