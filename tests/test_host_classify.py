@@ -363,3 +363,29 @@ def test_sharded_classify_world2_gloo(fake_gpu, tmp_path):
     n0, rows0 = json.load(open(str(tmp_path / "dist") + ".ret0"))
     assert n0 == n1 and [list(map(str, r)) for r in rows0] == [list(map(str, r)) for r in rows1]
     assert json.load(open(str(tmp_path / "dist") + ".ret1")) == [145, []]
+
+
+def test_command_line_classify_and_its_argument_errors(fake_gpu, monkeypatch, tmp_path, capsys):
+    """`python -m stag_amd classify ...` (stag/__main__.py:393-422): flags, defaults, the output file,
+    and the usage errors (exit status 1 with the reference's message)."""
+    from stag_amd.__main__ import main
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)
+    db = tmp_path / "db.stagDB"
+    db.write_text("placeholder: load_db is replaced")
+    out = tmp_path / "cli.tsv"
+    main(["classify", "-d", str(db), "-s", ali, "-o", str(out), "-v", "1"])
+    assert out.read_text() == g["runs"]["short"]["file"]
+    main(["classify", "-d", str(db), "-s", ali, "-o", str(out), "-v", "1", "-l"])
+    assert out.read_text().splitlines()[0] == g["runs"]["long"]["file"].splitlines()[0]
+    capsys.readouterr()
+    for argv, message in ((["classify", "-d", str(db)], "missing <fasta_seqs> (-i) or <aligned_seq> (-s)"),
+                          (["classify", "-s", ali], "missing <database> (-d)"),
+                          (["classify", "-d", str(db), "-s", ali, "-t", "0"], "number of threads (-t) is less than 1"),
+                          (["classify", "-d", str(db), "-s", ali, "-m", "101"], "-m should be between 0 and 100"),
+                          (["classify_genome", "-d", str(db), "-o", str(tmp_path / "g")], "you need to provide at least -i, -D, or -G."),
+                          (["classify_genome", "-d", str(db), "-G", ali, "-i", ali, "-o", str(tmp_path / "g")],
+                           "options -i, -D, and -G are mutually exclusive"),
+                          (["classify_genome", "-d", str(db), "-G", ali], "missing output directory (-o)")):
+        with pytest.raises(SystemExit) as e:
+            main(argv)
+        assert e.value.code == 1 and "[E::main] Error: " + message in capsys.readouterr().err
