@@ -55,6 +55,7 @@ def _classify_prealigned(db, aligned_sequences, tagged, state):
     batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
                                     slow_line=parse_onehot_line)
     for b, (ids, bits, n_fields) in enumerate(batches):
+        state["batch"] = b
         if not state["alignment_length"]:
             state["alignment_length"] = int(n_fields[0])
         if parallel.owner_of_batch(b, world) != rank:
@@ -104,7 +105,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
     if verbose > 2:
         sys.stderr.write("Load database: " + str("{0:.2f}".format(time_after_loading - t0)) + " sec\n")
 
-    state = {"alignment_length": None}
+    state = {"alignment_length": None, "batch": 0}
     tagged = []          # (batch index, rows) of the batches this rank classified
     n_pass = n_not_pass = 0
     error = None
@@ -122,6 +123,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
             alignment_out = open(save_ali_to_file, "wb") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
             with alignment_out:
                 for b, (ids, text, offs, gene) in enumerate(batches):
+                    state["batch"] = b
                     mine = parallel.owner_of_batch(b, world) == rank
                     if not mine and not (save_ali_to_file and rank == 0) and state["alignment_length"]:
                         continue
@@ -162,7 +164,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
         db.close()
     if error is not None:
         os.remove(hmm_file_path)
-    list_to_print = parallel.gather_in_order(tagged, error)
+    list_to_print = parallel.gather_in_order(tagged, error, state["batch"])
     if rank != 0:
         os.remove(hmm_file_path)
         return state["alignment_length"], []

@@ -31,10 +31,11 @@ def owner_of_batch(batch_index, world):
     return batch_index % world
 
 
-def gather_in_order(tagged_rows, error=None):
+def gather_in_order(tagged_rows, error=None, error_batch=0):
     """tagged_rows: list of (batch_index, rows) produced by this rank.  Returns, on rank 0, the rows
     of all ranks flattened in batch order; on other ranks an empty list.  If any rank passes
-    an exception in ``error`` every rank raises it (so that no rank waits for a dead peer)."""
+    an exception in ``error`` every rank raises (so that no rank waits for a dead peer) the one
+    from the earliest batch (``error_batch``), which is where the reference's single loop stops."""
     world, rank = world_rank()
     if world == 1:
         if error is not None:
@@ -42,10 +43,10 @@ def gather_in_order(tagged_rows, error=None):
         return [r for _, rows in sorted(tagged_rows, key=lambda t: t[0]) for r in rows]
     import torch.distributed as dist
     errors = [None] * world
-    dist.all_gather_object(errors, error)
-    for e in errors:
-        if e is not None:
-            raise e
+    dist.all_gather_object(errors, None if error is None else (error_batch, error))
+    failed = [e for e in errors if e is not None]
+    if failed:
+        raise min(failed, key=lambda t: t[0])[1]
     gathered = [None] * world if rank == 0 else None
     dist.gather_object(tagged_rows, gathered, dst=0)
     if rank != 0:

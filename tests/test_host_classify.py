@@ -363,6 +363,22 @@ def test_sharded_classify_world2_gloo(fake_gpu, tmp_path):
     n0, rows0 = json.load(open(str(tmp_path / "dist") + ".ret0"))
     assert n0 == n1 and [list(map(str, r)) for r in rows0] == [list(map(str, r)) for r in rows1]
     assert json.load(open(str(tmp_path / "dist") + ".ret1")) == [145, []]
+    # two malformed rows, one in a batch of each rank (READER_BATCH = 7: r9 is in batch 1, rank 1; r16 in
+    # batch 2, rank 0): both ranks stop with the error of the EARLIER one, as the reference's single loop would
+    bad = list(lines)
+    bad[16] = "r16\t0\t1"
+    bad[9] = "r9\t1\t0\t0"
+    ali.write_text("\n".join(bad) + "\n")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    code = WORKER.format(root=ROOT, port=port, db=TINY, ali=str(ali), out=str(tmp_path / "dist2"))
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode != 0 and "ValueError" in err.decode() and "[sequence r9]" in err.decode(), err.decode()[-2000:]
+    assert not os.path.exists(str(tmp_path / "dist2") + ".rank0")
 
 
 def test_command_line_classify_and_its_argument_errors(fake_gpu, monkeypatch, tmp_path, capsys):
