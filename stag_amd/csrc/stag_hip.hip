@@ -643,8 +643,8 @@ int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len
          hipMemcpy(d_itab.p, words_per_row, n_genes * 4, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(d_itab.p + n_genes, src_row, (size_t)n_genomes * n_genes * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return done(fail(STAG_E_HIP, "host to device copy failed"));
-    if (n_genomes > 65535) return done(fail(STAG_E_INVALID, "more than 65535 genomes in one call: split the batch"));
-    hipLaunchKernelGGL(k_concat_bits, dim3((unsigned)((db->W + 255) / 256), (unsigned)n_genomes), dim3(256), 0, nullptr, n_genomes,
+    if (n_genomes > 0x7fffffff || (db->W + 255) / 256 > 65535) return done(fail(STAG_E_INVALID, "batch too large"));
+    hipLaunchKernelGGL(k_concat_bits, dim3((unsigned)n_genomes, (unsigned)((db->W + 255) / 256)), dim3(256), 0, nullptr, n_genomes,
                        n_genes, d_tab.p, d_tab.p + n_genes + 1, d_itab.p, d_itab.p + n_genes, arena.p, db->bits.p, db->W);
     if ((rc = launch_check("k_concat_bits"))) return done(rc);
     if ((rc = walk_dev(db, db->bits.p, n_genomes, nullptr, resolve(db, nullptr), true, nullptr))) return done(rc);

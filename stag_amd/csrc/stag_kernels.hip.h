@@ -435,8 +435,8 @@ __global__ __launch_bounds__(256) void k_concat_bits(int64_t n_genomes, int n_ge
                                                      const int32_t *__restrict__ src_row,
                                                      const uint32_t *__restrict__ arena, uint32_t *__restrict__ out,
                                                      int W_out) {
-    const int w = blockIdx.x * 256 + threadIdx.x;
-    const int64_t j = blockIdx.y;
+    const int w = blockIdx.y * 256 + threadIdx.x;   // genomes along x: a grid's x extent has no practical bound
+    const int64_t j = blockIdx.x;
     if (w >= W_out || j >= n_genomes) return;
     const int64_t lo = 32ll * w, hi = lo + 32;
     int a = 0, b = n_genes;   // first gene whose bits end after lo

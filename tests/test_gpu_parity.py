@@ -519,3 +519,27 @@ def test_encode_at_the_row_width_limit():
         assert np.array_equal(dense[i, :5 * ncol], exp)
     with pytest.raises(_lib.StagError, match="too large"):
         encode_raw(["ACGT"], 5 * 70000)
+
+
+def test_classify_concat_more_genomes_than_a_grid_dimension():
+    """70,000 genomes in one call (more than the 65,535 a grid's y extent holds)."""
+    rng = np.random.default_rng(70)
+    gene_len = [10, 25, 5]
+    L = sum(gene_len)
+    taxonomy, tax_function, classifiers = random_db(rng, L // 5, [[3], [2, 2, 2]], 0.3)
+    n_genomes = 70000
+    dense = [rng.random((500, g)) < 0.3 for g in gene_len]
+    gene_rows = [tables.pack_bool_rows(X, tables.words_per_row(g)) for X, g in zip(dense, gene_len)]
+    src = rng.integers(-1, 500, size=(n_genomes, len(gene_len))).astype(np.int32)
+    want = np.zeros((n_genomes, L), dtype=bool)
+    at = 0
+    for p, g in enumerate(gene_len):
+        ok = src[:, p] >= 0
+        want[ok, at:at + g] = dense[p][src[ok, p]]
+        at += g
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        res = db.classify_concat(gene_len, gene_rows, src, want_bits=True)
+        assert np.array_equal(tables.unpack_rows(res.bits, L), want)
+        ref = db.classify_onehot(want)
+        for f in ("status", "n_aligned", "path_len", "selected", "path_node", "path_prob", "level_prob"):
+            assert np.array_equal(getattr(res, f), getattr(ref, f)), f
