@@ -105,7 +105,10 @@ int32_t stag_words_per_row(int32_t n_features);
 /*
  * align.py:37-58 + :160.  text holds n aligned (A2M) strings back to back; string i is
  * text[offs[i] .. offs[i+1]).  Bytes 0x0a..0x0d ('\n', '\v', '\f', '\r') inside a string are
- * skipped (A2M records may be line-wrapped; helpers.py:112 strips them).  Output row i (words_per_row words) has bit f set
+ * skipped (A2M records may be line-wrapped; helpers.py:112 strips them).  One byte is one character:
+ * 'a'..'z' are insert states and are dropped (align.py:47), every other byte is a column.  A caller whose
+ * strings can hold letters outside ASCII (for which the reference asks str.islower()) passes a stand-in of
+ * the same class instead, as stag_amd.tables.ascii_stand_in does.  Output row i (words_per_row words) has bit f set
  * iff one-hot feature f of string i is True: word f>>5, bit f&31.  For the _dev form, d_text is a
  * 16-byte aligned buffer of text_bytes bytes, text_bytes a multiple of 16 and >= offs[n] (pad it).
  * status: OK, ZERO_COLUMNS,

@@ -57,7 +57,9 @@ def gen_encode():
     rng = np.random.default_rng(1)
     cases = ["ACGTU", "acgtu", "-", ".", "N", "ACGTUacgtu-.N*RYKMSWBDHVn", "-----", "A", "a",
              "", "ac.gt", "AC-GT..NNacgtACGU--", "*", "ACGT" * 40 + "acg" + "-" * 7,
-             "U" * 64, "-" * 63 + "A", "ac" * 5 + "G", "AcCgGtTuU-", "XZ@[`{|}~ 09azAZ"]
+             "U" * 64, "-" * 63 + "A", "ac" * 5 + "G", "AcCgGtTuU-", "XZ@[`{|}~ 09azAZ",
+             # characters outside ASCII: str.islower() decides (align.py:47), everything else is a column
+             "AC\u00e9GT\u00c9-\u00df\u4e2dN\u00aa\u01c5G", "\u00e9\u00e8"]
     alphabet = list("ACGTU-.N") + list("acgtn") + list("RYKM*")
     p = np.array([6, 6, 6, 6, 2, 8, 1, 1] + [0.4] * 5 + [0.2] * 5, dtype=float)
     p /= p.sum()
@@ -83,6 +85,8 @@ def gen_backtranslate():
         ("M-KV", "ATGAAAGTT"),
         ("-M-K-V-", "ATGAAAGTTTGA"),
         ("MkV", "ATGAAAGTT"),              # lowercase residue consumed, not emitted
+        ("M\u00e9K\u00c9V\u4e2d", "ATGAAAGTTCCCGGGTTT"),   # outside ASCII: isupper / islower decide (align.py:82-86)
+        ("MK", "AT\u00e9AAA"),             # the gene's characters are copied as they are
         ("mkv", "ATGAAAGTT"),
         ("--", ""),
         ("M.KV", "ATGAAAGTTCCC"),          # '.' counts as a residue for the length check, emits nothing

@@ -53,9 +53,18 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def _as_bytes(text):
+    """The C restatement reads one byte per character.  The reference classifies characters with str
+    methods (align.py:47,82-86), which know letters outside ASCII too: such a character is handed to C
+    as an ASCII byte of the same class ('x' lower case, 'X' upper case, '?' neither)."""
+    if text.isascii():
+        return text.encode("ascii")
+    return bytes(ord(c) if ord(c) < 128 else (0x78 if c.islower() else 0x58 if c.isupper() else 0x3F) for c in text)
+
+
 def encode_a2m(text):
     """-> (bool[5*n_char], n_char, n_aligned)."""
-    raw = text.encode("latin-1")
+    raw = _as_bytes(text)
     bits = np.zeros(5 * max(len(raw), 1), dtype=np.uint8)
     n_al = ctypes.c_int64(0)
     n_char = lib().oracle_encode_a2m(raw, len(raw), _ptr(bits), ctypes.byref(n_al))
@@ -67,7 +76,7 @@ def passes_filter(n_aligned, n_char, min_perc):
 
 
 def protein2gene(prot, gene, check_length=True):
-    p, g = prot.encode("latin-1"), gene.encode("latin-1")
+    p, g = _as_bytes(prot), _as_bytes(gene)     # (a gene character outside ASCII comes back as its stand-in)
     out = ctypes.create_string_buffer(3 * len(p) + 4)
     n = lib().oracle_protein2gene(p, len(p), g, len(g), int(check_length), out)
     return None if n < 0 else out.raw[:n].decode("latin-1")

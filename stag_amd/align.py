@@ -19,8 +19,10 @@ BATCH_RECORDS = 1 << 16      # records handed to the GPU at a time
 
 def protein2gene_alignment(gene_id, protein_alignment, gene_sequence, check_length=True):
     """align.py:63-94 via libstag_hip's host entry point.  None when the lengths do not fit."""
-    p = protein_alignment.encode("latin-1", "replace")
-    g = gene_sequence.encode("latin-1", "replace")
+    if not (protein_alignment.isascii() and gene_sequence.isascii()):
+        return _protein2gene_alignment_py(gene_id, protein_alignment, gene_sequence, check_length)
+    p = protein_alignment.encode("ascii")
+    g = gene_sequence.encode("ascii")
     out = ctypes.create_string_buffer(3 * len(p) + 4)
     n = ctypes.c_int64(0)
     _lib.check(_lib.lib().stag_backtranslate(p, len(p), g, len(g), int(bool(check_length)), out, ctypes.byref(n)))
@@ -30,7 +32,27 @@ def protein2gene_alignment(gene_id, protein_alignment, gene_sequence, check_leng
         sys.stderr.write(" (protein: " + str(n_res * 3) + ", gene: " + str(len(g)) + ")\n")
         sys.stderr.write(" ID: " + gene_id + "\n")
         return None
-    return out.raw[:n.value].decode("latin-1")
+    return out.raw[:n.value].decode("ascii")
+
+
+def _protein2gene_alignment_py(gene_id, protein_alignment, gene_sequence, check_length):
+    """The same for strings with characters outside ASCII (str.isupper / islower decide, as in the reference)."""
+    n_res = len(protein_alignment) - protein_alignment.count("-")
+    if check_length and len(gene_sequence) not in (3 * n_res, 3 * n_res + 3):
+        sys.stderr.write("Error, length of genes/alignment is not correct")
+        sys.stderr.write(" (protein: " + str(n_res * 3) + ", gene: " + str(len(gene_sequence)) + ")\n")
+        sys.stderr.write(" ID: " + gene_id + "\n")
+        return None
+    out, at = [], 0
+    for ch in protein_alignment:
+        if ch == "-":
+            out.append("---")
+        elif ch.isupper():
+            out.append(gene_sequence[at:at + 3])
+            at += 3
+        elif ch.islower():
+            at += 3
+    return "".join(out)
 
 
 def _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose):

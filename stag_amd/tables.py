@@ -132,9 +132,20 @@ def words_per_row(n_features):
     return max(((n_features + 31) // 32 + 3) // 4 * 4, 4)
 
 
+def ascii_stand_in(s):
+    """One byte per CHARACTER of an aligned string, as the kernels read it.  The reference classifies
+    characters with str methods (align.py:47 `islower`, :82-86 `isupper` / `islower`), which also accept
+    letters outside ASCII; such a character travels as an ASCII stand-in of the same class -- 'x' (a lower-case
+    letter: an insert state), 'X' (an upper-case letter) or '?' (anything else) -- so that the byte-wise
+    kernels decide as the reference does.  ASCII strings (every real alignment) pass through unchanged."""
+    if s.isascii():
+        return s.encode("ascii")
+    return "".join(c if c.isascii() else "x" if c.islower() else "X" if c.isupper() else "?" for c in s).encode("ascii")
+
+
 def pack_text(strings):
     """list[str] -> (uint8 text buffer, int64 offsets[n+1]) for the *_a2m entry points."""
-    raw = [s.encode("latin-1", "replace") if isinstance(s, str) else bytes(s) for s in strings]
+    raw = [ascii_stand_in(s) if isinstance(s, str) else bytes(s) for s in strings]
     offs = np.zeros(len(raw) + 1, dtype=np.int64)
     if raw:
         np.cumsum([len(r) for r in raw], out=offs[1:])

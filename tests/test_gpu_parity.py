@@ -349,7 +349,9 @@ def test_backtranslate_dev_golden_and_random(capfd):
         cases = [c for c in g if c["check_length"] == check]
         got, st = backtranslate_gpu([(c["protein"], c["gene"]) for c in cases], check)
         for c, r, s in zip(cases, got, st):
-            assert r == c["result"], c
+            # characters outside ASCII travel as stand-ins of their class (tables.ascii_stand_in)
+            want = c["result"] if c["result"] is None else tables.ascii_stand_in(c["result"]).decode()
+            assert r == want, c
             assert s == (_lib.SEQ_BACKTRANSLATE if c["result"] is None else 0)
     rng = np.random.default_rng(123)
     pairs = []

@@ -34,8 +34,13 @@ def test_words_per_row():
     assert f(1) == 4 and f(128) == 4 and f(129) == 8 and f(7500) == 236 and f(145) == 8
 
 
-def test_backtranslate_golden():
+def test_backtranslate_golden(capfd):
+    from stag_amd.align import protein2gene_alignment
     for case in gu.load("backtranslate.json"):
+        # the Python-level function takes any string; the C ABI one byte per character (ASCII)
+        assert protein2gene_alignment("id", case["protein"], case["gene"], case["check_length"]) == case["result"], case
+        if not (case["protein"].isascii() and case["gene"].isascii()):
+            continue
         p, g = case["protein"].encode(), case["gene"].encode()
         out = ctypes.create_string_buffer(3 * len(p) + 4)
         n = ctypes.c_int64(0)

@@ -159,8 +159,9 @@ def test_fasta_scan_random_streams_equal_the_python_reader():
             chunk = int(rng.choice([1, 2, 5, 17, 4096]))
             batch = int(rng.choice([1, 3, 1 << 16]))
             # sequence text travels one byte per CHARACTER (a character is one column for the reference):
-            # a non-ASCII character becomes its latin-1 byte or '?', never an A/C/G/T/U
-            want = [[i, s.encode("latin-1", "replace")] for i, s in want]
+            # a non-ASCII character becomes an ASCII stand-in of its class (tables.ascii_stand_in)
+            from stag_amd.tables import ascii_stand_in
+            want = [[i, ascii_stand_in(s)] for i, s in want]
             got = []
             for ids, text, offs in ingest.fasta_batches(io.BytesIO(data), batch_records=batch, chunk_bytes=chunk,
                                                         text_mode=text_mode):
