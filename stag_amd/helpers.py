@@ -40,6 +40,7 @@ def check_file_exists(file_name, isfasta=False):
         with open(file_name, "r") as fh:
             if isfasta and not fh.readline().startswith(">"):
                 sys.stderr.write("[E::main] Error: Not a fasta file: " + file_name + "\n")
+                sys.stderr.write("          Fasta file is expected to start with '>'\n")
                 sys.exit(1)
     except Exception as e:
         sys.stderr.write("[E::main] Error: Cannot open file: " + file_name + "\n" + str(e) + "\n")
