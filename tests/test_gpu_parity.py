@@ -545,3 +545,16 @@ def test_classify_concat_more_genomes_than_a_grid_dimension():
         ref = db.classify_onehot(want)
         for f in ("status", "n_aligned", "path_len", "selected", "path_node", "path_prob", "level_prob"):
             assert np.array_equal(getattr(res, f), getattr(ref, f)), f
+
+
+def test_fuzz_sample():
+    """The first 120 configurations of tools/fuzz_gpu.py (random trees, widths, reads, filters, arbitrary
+    bit rows, protein pairs, output text) -- the long runs are recorded in DESIGN.md."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tools", "fuzz_gpu.py")
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for seed in range(120):
+        mod.one(seed)
