@@ -137,6 +137,24 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
                           int64_t n, double min_perc_state, const stag_results_t *d_out, void *stream);
 
 /*
+ * NO COUNTERPART IN THE REFERENCE.  stag_classify_a2m_dev for callers that cannot allocate device
+ * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
+ * arguments, same kernels, same results, but the call allocates nothing (no hipMalloc, hipFree or
+ * event creation): its workspace -- packed rows, grouping arrays, level records, and a stand-in for
+ * every output pointer left NULL -- is carved out of one static device array of
+ * STAG_NOALLOC_SCRATCH_BYTES per GPU (held from library load until the process ends; its address is
+ * looked up by stag_db_create).  A batch whose workspace does not fit is refused with STAG_E_INVALID
+ * and a message naming the bytes it would need: about n * (4 * words_per_row + 16 * max_depth + 40)
+ * + 544 * (widest tree level + 2) + 8 * n_nodes bytes when every output pointer is given (~56,000
+ * reads of a 1,500-column, 7-rank, 20,000-node database).  All calls on one GPU share that array,
+ * whatever their handle: calls that overlap on one GPU (two streams, two threads) race; it keeps
+ * the previous call's contents, and everything that must start at zero is cleared by the call.
+ */
+#define STAG_NOALLOC_SCRATCH_BYTES (64 * 1024 * 1024)
+int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
+                                  int64_t n, double min_perc_state, const stag_results_t *d_out, void *stream);
+
+/*
  * align.py:63-94 on the GPU for n (protein alignment, gene) pairs laid out like the A2M text
  * (record i = text[offs[i] .. offs[i+1])).  Record i's codon alignment is written to
  * d_out[d_out_begin[i] .. d_out_end[i]) with d_out_begin[i] = 3 * prot_offs[i]; d_out must hold

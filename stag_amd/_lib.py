@@ -53,6 +53,8 @@ EXPORTS = {
                                          ctypes.POINTER(Results), c_p, c_p]),
     "stag_classify_a2m_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.c_int64, ctypes.c_double,
                                              ctypes.POINTER(Results), c_p]),
+    "stag_classify_a2m_noalloc_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.c_int64, ctypes.c_double,
+                                                     ctypes.POINTER(Results), c_p]),
     "stag_backtranslate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,
                                           ctypes.c_int32, ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64)]),
     "stag_backtranslate_dev": (ctypes.c_int, [c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int64, ctypes.c_int32, c_p,

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -62,6 +63,46 @@ struct ProfRec {
     int cls;
 };
 
+// Everything one call needs on the device beyond its inputs and outputs.  A handle fills it from
+// its own (growing) buffers; stag_classify_a2m_noalloc_dev carves it from `scratch` below.
+struct Work {
+    int32_t *node, *pos, *count, *task_off, *n_tasks;
+    SeqRef *order;
+    LevelRec *lvl;
+    Task *tasks;
+    uint32_t *win;
+    uint32_t *bits;                       // encode's packed rows (text entry points only)
+    int32_t *enc_n_char, *enc_status;     // likewise
+    bool prof;                            // bracket launches with events (allocates: never on the no-allocation path)
+};
+
+size_t walk_max_tasks(int64_t n, int max_level_nodes) { return (size_t)n / TILE + max_level_nodes + 2; }
+
+}  // namespace
+
+// ---- stag_classify_a2m_noalloc_dev: the workspace of callers that cannot allocate.  One copy per
+// GPU, held until the process ends; in host code this NAME is only a stand-in for the symbol, the
+// device address comes from hipGetSymbolAddress (scratch_of) and is what kernels and memsets get.
+static __device__ __align__(256) unsigned char scratch[STAG_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mu;
+unsigned char *g_scratch_ptr[MAX_DEVICES] = {};
+
+// Device address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+int scratch_of(int device, unsigned char **out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(STAG_E_INVALID, "device %d out of range", device);
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(STAG_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return STAG_OK;
+}
 }  // namespace
 
 struct stag_db {
@@ -116,7 +157,7 @@ struct Prof {  // brackets one launch with events when profiling is on
     hipStream_t st;
     ProfRec r{};
     bool on;
-    Prof(stag_db *d, hipStream_t s, int cls) : db(d), st(s), on(d && d->prof) {
+    Prof(stag_db *d, hipStream_t s, int cls, bool enabled = true) : db(d), st(s), on(d && d->prof && enabled) {
         if (!on) return;
         r.cls = cls;
         if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
@@ -210,7 +251,7 @@ int reserve_walk(stag_db *db, int64_t n) {
     int rc;
     if ((rc = db->node.reserve(n))) return rc;
     if ((rc = db->pos.reserve(n))) return rc;
-    const size_t max_tasks = (size_t)n / TILE + db->max_level_nodes + 2;
+    const size_t max_tasks = walk_max_tasks(n, db->max_level_nodes);
     if ((rc = db->order.reserve(max_tasks * TILE))) return rc;   // 64 slots per task
     if ((rc = db->lvl.reserve((size_t)std::max(db->max_depth, 1) * n))) return rc;
     if ((rc = db->win.reserve(n))) return rc;
@@ -221,6 +262,15 @@ int reserve_walk(stag_db *db, int64_t n) {
     if ((rc = reserve_results(db, n))) return rc;
     db->cap_n = std::max(db->cap_n, n);
     return STAG_OK;
+}
+
+Work work_of(stag_db *db) {
+    Work w;
+    w.node = db->node.p; w.pos = db->pos.p; w.count = db->count.p; w.task_off = db->task_off.p; w.n_tasks = db->n_tasks.p;
+    w.order = db->order.p; w.lvl = db->lvl.p; w.tasks = db->tasks.p; w.win = db->win.p;
+    w.bits = db->bits.p; w.enc_n_char = db->enc_n_char.p; w.enc_status = db->enc_status.p;
+    w.prof = true;
+    return w;
 }
 
 Out resolve(stag_db *db, const stag_results_t *o) {
@@ -238,7 +288,7 @@ Out resolve(stag_db *db, const stag_results_t *o) {
 
 // The level-synchronous walk + rank cut on device rows.  n_aligned must already be filled
 // (encode) unless count_aligned is set.
-int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in, const Out &o,
+int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in, const Out &o,
              bool count_aligned, hipStream_t st) {
     if (n == 0) return STAG_OK;
     if (n > 0x7fffffff - 1024) return fail(STAG_E_INVALID, "batch of %lld sequences is too large; split it", (long long)n);
@@ -246,13 +296,13 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     const int D = std::max(db->max_depth, 1);
     const unsigned g256 = (unsigned)((n + 255) / 256);
     if (count_aligned) {
-        Prof p(db, st, 4);
+        Prof p(db, st, 4, wk.prof);
         hipLaunchKernelGGL(k_count_aligned, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_bits, n, db->L, db->W,
-                           o.n_aligned, db->win.p);
+                           o.n_aligned, wk.win);
     }
     {
-        Prof p(db, st, 2);
-        HIP_TRY(hipMemsetAsync(db->count.p, 0, sizeof(int32_t) * db->n_nodes, st));
+        Prof p(db, st, 2, wk.prof);
+        HIP_TRY(hipMemsetAsync(wk.count, 0, sizeof(int32_t) * db->n_nodes, st));
         if (db->max_depth == 0)
             hipLaunchKernelGGL(k_init_status, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status);
     }
@@ -260,44 +310,44 @@ int walk_dev(stag_db *db, const uint32_t *d_bits, int64_t n, const int32_t *d_st
     if ((rc = launch_check("k_init_status"))) return rc;
     for (int d = 0; d < db->max_depth; ++d) {
         const int lo = db->level_start[d], hi = db->level_start[d + 1];
-        LevelRec *cur = db->lvl.p + (size_t)d * n;
+        LevelRec *cur = wk.lvl + (size_t)d * n;
         if (d == 0) {
-            Prof p(db, st, 2);
-            hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, db->win.p, cur,
-                               db->child_first.p, db->node_err.p, db->order.p, db->tasks.p, db->n_tasks.p);
+            Prof p(db, st, 2, wk.prof);
+            hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, wk.win, cur,
+                               db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks);
         } else {
-            Prof p(db, st, 2);
+            Prof p(db, st, 2, wk.prof);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
-                               n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, db->node.p,
-                               db->count.p, db->pos.p);
-            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, db->count.p, db->task_off.p,
-                               db->n_tasks.p + d);
-            hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, db->node.p, db->pos.p, db->count.p,
-                               db->task_off.p, db->child_first.p, db->node_err.p, db->win.p, db->order.p, db->tasks.p);
+                               n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, wk.node,
+                               wk.count, wk.pos);
+            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, wk.count, wk.task_off,
+                               wk.n_tasks + d);
+            hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, wk.node, wk.pos, wk.count,
+                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
         a.bits = d_bits; a.W = db->W; a.NC = db->nchunks;
-        a.n_tasks = db->n_tasks.p + d; a.tasks = db->tasks.p; a.order = db->order.p;
+        a.n_tasks = wk.n_tasks + d; a.tasks = wk.tasks; a.order = wk.order;
         a.intercept = db->intercept.p;
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p;
         a.lvl = cur; a.status = o.status;
         a.gappre = db->gappre.p; a.gapsuf = db->gapsuf.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         {
-            Prof p(db, st, 1);
+            Prof p(db, st, 1, wk.prof);
             hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
         }
         if ((rc = launch_check("k_walk_level"))) return rc;
     }
     {
-        Prof p(db, st, 3);
+        Prof p(db, st, 3, wk.prof);
         const size_t lds = (size_t)256 * ((D + db->n_keys) * sizeof(double) + D * sizeof(int32_t));
         if (lds > 160 * 1024) return fail(STAG_E_INVALID, "tree depth %d + %d rank-cut keys exceed the rank-cut kernel's LDS tile", D, db->n_keys);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_rankcut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), lds, st, n, D, db->max_depth, db->n_keys, db->n_tf, db->tf.p,
-                           db->lvl.p, o.path_node, o.path_prob, o.path_len, o.lead, o.level_prob, o.selected, o.status);
+                           wk.lvl, o.path_node, o.path_prob, o.path_len, o.lead, o.level_prob, o.selected, o.status);
     }
     return launch_check("k_rankcut");
 }
@@ -358,6 +408,10 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
             return fail(STAG_E_INVALID, "child_first not monotone / not breadth-first at node %d", i);
     int rc = check_device(device);
     if (rc) return rc;
+    {   // per-device set-up: the address of this GPU's copy of `scratch` (device is current here)
+        unsigned char *sp = nullptr;
+        if ((rc = scratch_of(device, &sp))) return rc;
+    }
 
     stag_db *db = new (std::nothrow) stag_db;
     if (!db) return fail(STAG_E_NOMEM, "out of host memory");
@@ -548,7 +602,7 @@ int stag_classify_bits_dev(stag_db_t *db, const uint32_t *d_bits, int64_t n, con
     HIP_TRY(hipSetDevice(db->device));
     int rc = reserve_walk(db, n);
     if (rc) return rc;
-    return walk_dev(db, d_bits, n, d_status_in, resolve(db, d_out), true, (hipStream_t)stream);
+    return walk_dev(db, work_of(db), d_bits, n, d_status_in, resolve(db, d_out), true, (hipStream_t)stream);
 }
 
 int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int32_t *status_in,
@@ -561,7 +615,7 @@ int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int
         return rc;
     HIP_TRY(hipMemcpy(db->bits.p, bits, (size_t)n * db->W * 4, hipMemcpyHostToDevice));
     if (status_in) HIP_TRY(hipMemcpy(db->enc_status.p, status_in, n * 4, hipMemcpyHostToDevice));
-    if ((rc = walk_dev(db, db->bits.p, n, status_in ? db->enc_status.p : nullptr, resolve(db, nullptr), true, nullptr)))
+    if ((rc = walk_dev(db, work_of(db), db->bits.p, n, status_in ? db->enc_status.p : nullptr, resolve(db, nullptr), true, nullptr)))
         return rc;
     return copy_results_to_host(db, out, n, nullptr);
 }
@@ -578,7 +632,66 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
     if ((rc = encode_dev(db, db->L, d_text, text_bytes, d_offs, n, min_perc_state, db->bits.p, db->enc_n_char.p,
                          o.n_aligned, db->enc_status.p, db->win.p, st)))
         return rc;
-    return walk_dev(db, db->bits.p, n, db->enc_status.p, o, false, st);
+    return walk_dev(db, work_of(db), db->bits.p, n, db->enc_status.p, o, false, st);
+}
+
+// Same kernels as stag_classify_a2m_dev; the workspace and any output the caller left NULL come out
+// of this GPU's `scratch` instead of the handle's hipMalloc'ed buffers.  No hipMalloc / hipFree /
+// event creation on this path.
+int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
+                                  double min_perc_state, const stag_results_t *d_out, void *stream) {
+    if (!db || n < 0 || (n > 0 && (!d_text || !d_offs))) return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    if (n > 0x7fffffff - 1024) return fail(STAG_E_INVALID, "batch of %lld sequences is too large; split it", (long long)n);
+    HIP_TRY(hipSetDevice(db->device));
+    unsigned char *base = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        base = db->device < MAX_DEVICES ? g_scratch_ptr[db->device] : nullptr;
+    }
+    if (!base) return fail(STAG_E_HIP, "the scratch array of device %d was not set up (stag_db_create does it)", db->device);
+    const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
+    const size_t max_tasks = walk_max_tasks(n, db->max_level_nodes);
+    size_t used = 0;
+    auto carve = [&](size_t bytes) {   // 256-byte aligned pieces, one after the other
+        unsigned char *p = base + used;
+        used += (bytes + 255) / 256 * 256;
+        return p;
+    };
+    Work wk;
+    wk.bits = (uint32_t *)carve((size_t)n * db->W * 4);
+    wk.lvl = (LevelRec *)carve(D * n * sizeof(LevelRec));
+    wk.order = (SeqRef *)carve(max_tasks * TILE * sizeof(SeqRef));
+    wk.tasks = (Task *)carve(max_tasks * sizeof(Task));
+    wk.node = (int32_t *)carve(n * 4);
+    wk.pos = (int32_t *)carve(n * 4);
+    wk.win = (uint32_t *)carve(n * 4);
+    wk.enc_n_char = (int32_t *)carve(n * 4);
+    wk.enc_status = (int32_t *)carve(n * 4);
+    wk.count = (int32_t *)carve((size_t)db->n_nodes * 4);
+    wk.task_off = (int32_t *)carve((size_t)db->n_nodes * 4);
+    wk.n_tasks = (int32_t *)carve(D * 4);
+    wk.prof = false;
+    Out o;   // outputs the caller does not want still have to land somewhere
+    o.path_node = d_out && d_out->path_node ? d_out->path_node : (int32_t *)carve(n * D * 4);
+    o.path_prob = d_out && d_out->path_prob ? d_out->path_prob : (double *)carve(n * D * 8);
+    o.path_len = d_out && d_out->path_len ? d_out->path_len : (int32_t *)carve(n * 4);
+    o.lead = d_out && d_out->n_lead_single ? d_out->n_lead_single : (int32_t *)carve(n * 4);
+    o.level_prob = d_out && d_out->level_prob ? d_out->level_prob : (double *)carve(n * K * 8);
+    o.selected = d_out && d_out->selected ? d_out->selected : (int32_t *)carve(n * 4);
+    o.n_aligned = d_out && d_out->n_aligned ? d_out->n_aligned : (int32_t *)carve(n * 4);
+    o.status = d_out && d_out->status ? d_out->status : (int32_t *)carve(n * 4);
+    if (used > (size_t)STAG_NOALLOC_SCRATCH_BYTES)
+        return fail(STAG_E_INVALID,
+                    "%lld sequences of this database need %lld bytes of workspace; the static scratch of "
+                    "stag_classify_a2m_noalloc_dev holds %lld (split the batch, or use stag_classify_a2m_dev)",
+                    (long long)n, (long long)used, (long long)STAG_NOALLOC_SCRATCH_BYTES);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = encode_dev(nullptr, db->L, d_text, text_bytes, d_offs, n, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
+                         wk.enc_status, wk.win, st)))
+        return rc;
+    return walk_dev(db, wk, wk.bits, n, wk.enc_status, o, false, st);
 }
 
 int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n, double min_perc_state,
@@ -647,7 +760,7 @@ int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len
     hipLaunchKernelGGL(k_concat_bits, dim3((unsigned)n_genomes, (unsigned)((db->W + 255) / 256)), dim3(256), 0, nullptr, n_genomes,
                        n_genes, d_tab.p, d_tab.p + n_genes + 1, d_itab.p, d_itab.p + n_genes, arena.p, db->bits.p, db->W);
     if ((rc = launch_check("k_concat_bits"))) return done(rc);
-    if ((rc = walk_dev(db, db->bits.p, n_genomes, nullptr, resolve(db, nullptr), true, nullptr))) return done(rc);
+    if ((rc = walk_dev(db, work_of(db), db->bits.p, n_genomes, nullptr, resolve(db, nullptr), true, nullptr))) return done(rc);
     if ((rc = copy_results_to_host(db, out, n_genomes, nullptr))) return done(rc);
     if (bits_out && hipMemcpy(bits_out, db->bits.p, (size_t)n_genomes * db->W * 4, hipMemcpyDeviceToHost) != hipSuccess)
         return done(fail(STAG_E_HIP, "device to host copy failed"));
@@ -692,7 +805,7 @@ int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t pro
     if ((rc = encode_dev(db, db->L, (const char *)db->bt_text.p, bt_bytes, db->bt_begin.p, n, min_perc_state, db->bits.p,
                          db->enc_n_char.p, o.n_aligned, db->enc_status.p, db->win.p, st, db->bt_end.p, db->bt_status.p)))
         return rc;
-    return walk_dev(db, db->bits.p, n, db->enc_status.p, o, false, st);
+    return walk_dev(db, work_of(db), db->bits.p, n, db->enc_status.p, o, false, st);
 }
 
 int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *prot_offs, const char *gene,
