@@ -154,6 +154,16 @@ def config_16s(seed=2, scale=1.0):
     return make_db(seed, 1500, sizes, 0.02, name="16S_C2")
 
 
+def config_c3(seed=3):
+    """C3: protein marker gene stagDB shape: ncol 1050 (350 aa x 3, L 5250), 7 ranks; reads cover every column."""
+    return make_db(seed, 1050, [4, 12, 40, 120, 300, 600, 900], 0.02, name="C3")
+
+
+def config_c5(seed=5):
+    """C5: synthetic ~50k-node taxonomy at the 16S width (ncol 1500, L 7500)."""
+    return make_db(seed, 1500, [6, 30, 200, 1000, 4000, 15000, 30000], 0.02, name="C5")
+
+
 def dense_rows(tables, node_ids=None):
     """Dense [n_nodes, 1+L] fp64 rows for the C oracle (only for node_ids if given, else all)."""
     n, L = tables.n_nodes, tables.n_features

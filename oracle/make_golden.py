@@ -16,6 +16,10 @@ What is called from the reference (zellerlab/stag 0.8.2):
                                                              -> tsv.json
   stag.classify_genome.concat_alignments (classify_genome.py:364-388) -> concat.json
   stag.databases.save_to_file           (databases.py:111-147) -> tiny.stagDB (+ tiny_db.json)
+  stag.create_db.train_all_classifiers_nonmp (create_db.py:127-145) on the bundled test sequences,
+  stag.alignment.load_alignment_from_file, stag.taxonomy3.Taxonomy        -> c1.stagDB, c1.json
+  stag.databases.save_to_file + the tar layout of train_genome.py:46-60,
+  stag.classify_genome.concat_alignments / merge_gene_predictions       -> genome3.stagDB, genome_db.json
   stag.helpers.read_fasta               (helpers.py:107-121) and
   stag.classify.alignment_reader        (classify.py:16-20)  -> ingest.json
 
@@ -437,6 +441,154 @@ def gen_stagdb():
         print("wrote tiny.stagDB", os.path.getsize(path), "bytes")
 
 
+# ---------------------------------------------------------------- C1 substitute: the bundled test sequences
+def gen_c1():
+    """BASELINE config 1 / SURVEY 8(c)6.  The reference's own known-answer test (stag_test_short.py:197-280)
+    trains on stag/test/{sequences.fasta, sequences.taxonomy, gene.hmm}, classifies the same 50 sequences and
+    wants every predicted lineage to equal the true one.  hmmalign is not installed here, so the alignment
+    is a fixed one: each sequence left-justified in the HMM's 29 columns.  Everything after the alignment is
+    the reference's code: convert_alignment, load_alignment_from_file, Taxonomy, ensure_geneset_consistency,
+    train_all_classifiers_nonmp (create_db.py:127-145: LogisticRegression(l1, liblinear) per node), save_to_file,
+    classify_seq.  learn_taxonomy_selection_function (create_db.py:278-408) does not run under this
+    container's pandas 2.x (SURVEY 8c), so the rank-cut rows are fixed ones that favour the deepest level;
+    the fixture says so."""
+    import logging
+    import stag.create_db as ref_create
+    from stag.alignment import load_alignment_from_file
+    from stag.taxonomy3 import Taxonomy
+    logging.disable(logging.CRITICAL)
+    test_dir = "/root/reference/stag/test"
+    ncol = 29
+    with open(os.path.join(test_dir, "sequences.fasta"), "rb") as fh:
+        seqs = list(ref_helpers.read_fasta(fh, head_start=1))
+    truth = dict(line.rstrip("\n").split("\t") for line in open(os.path.join(test_dir, "sequences.taxonomy")))
+    aligned = [(sid, s.upper() + "-" * (ncol - len(s))) for sid, s in seqs]
+    assert all(len(a) == ncol for _, a in aligned)
+    with tempfile.TemporaryDirectory() as tmp:
+        ali_file = os.path.join(tmp, "ali.tsv")
+        with open(ali_file, "w") as fh:
+            for sid, a in aligned:
+                x, _ = ref_align.convert_alignment(a, 1, as_numpy=True)
+                fh.write(sid + "\t" + "\t".join("1" if b else "0" for b in x) + "\n")
+        alignment = load_alignment_from_file(ali_file)          # drops duplicated rows, as training does
+        full = Taxonomy(os.path.join(test_dir, "sequences.taxonomy"))
+        full.load_from_file()
+        full.ensure_geneset_consistency(list(alignment.index.values))
+        with contextlib.redirect_stdout(io.StringIO()):
+            classifiers = ref_create.train_all_classifiers_nonmp(alignment, full, "l1", "liblinear")
+        tf_note = "fixed rows (the reference's rank-cut training does not run under pandas 2.x here)"
+        tf = {-1: _Model(np.array([-4.0, 0.0, 0.0])), 0: _Model(np.array([-2.0, 1.0, 0.0])),
+              1: _Model(np.array([-1.0, 1.5, 2.5]))}
+        path = os.path.join(OUT, "c1.stagDB")
+        ref_db.save_to_file(classifiers, full, tf, False, path,
+                            hmm_file_path=os.path.join(test_dir, "gene.hmm"), protein_fasta_input=None)
+        taxonomy = {n: list(full[n].children.keys()) for n, _ in full.get_all_nodes(get_root=True)}
+        cls = {k: (m if isinstance(m, str) else np.append(m.intercept_, m.coef_)) for k, m in classifiers.items()}
+        tfd = {str(k): np.append(m.intercept_, m.coef_) for k, m in tf.items()}
+        rows = []
+        for sid, a in aligned:
+            x, _ = ref_align.convert_alignment(a, 1, as_numpy=True)
+            rows.append([str(v) for v in ref_classify.classify_seq(sid, x, taxonomy, tfd, cls, 1, 1)])
+    n_right = sum(r[1] == truth[r[0]] for r in rows)
+    dump("c1.json", {"ids": [sid for sid, _ in aligned], "sequences": [s for _, s in seqs],
+                     "aligned": [a for _, a in aligned], "true_lineage": [truth[sid] for sid, _ in aligned],
+                     "reference_rows": rows, "rank_cut": tf_note, "n_nodes": len(taxonomy),
+                     "n_trained": sum(not isinstance(m, str) for m in classifiers.values())})
+    print("wrote c1.stagDB", os.path.getsize(path), "bytes;", n_right, "of", len(rows), "lineages equal the taxonomy file")
+
+
+# ---------------------------------------------------------------- genome database (a14 layout)
+def gen_genome_db():
+    """A genome .stagDB in the layout of train_genome.py:46-60 -- a gztar of one HDF5 per marker gene (written
+    by the reference's save_to_file), threshold_file.tsv (its order is the concatenation order),
+    hmm_lengths_file.tsv and concatenated_genes_STAG_database.HDF5 -- plus what the reference's
+    concat_alignments + classify_seq give for a set of marker-gene alignments (genome_db.json)."""
+    import tarfile
+    from stag.taxonomy3 import Taxonomy
+    rng = np.random.default_rng(414)
+    ncols = {"COG0012": 12, "COG0016": 9, "COG0018": 15}
+    order = ["COG0016", "COG0012", "COG0018"]                  # threshold-file order, not alphabetical
+    lineages = ["g1\tBacteria;Firmicutes;Bacilli", "g2\tBacteria;Firmicutes;Clostridia",
+                "g3\tBacteria;Bacteroidetes;Bacteroidia", "g4\tBacteria;Proteobacteria;Alpha",
+                "g5\tBacteria;Proteobacteria;Gamma", "g6\tArchaea;Euryarchaeota;Halobacteria",
+                "g7\tArchaea;Euryarchaeota;Methanococci"]
+    dbs = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        taxfile = os.path.join(tmp, "tax.tsv")
+        with open(taxfile, "w") as fh:
+            fh.write("\n".join(lineages) + "\n")
+
+        def write_db(name, L, seed_scale):
+            full = Taxonomy(taxfile)
+            full.load_from_file()
+            classifiers = {}
+            for n, sibs in full.get_all_nodes(get_root=False):
+                row = rng.normal(0, seed_scale, size=1 + L) * (rng.random(1 + L) < 0.25)
+                row[0] = rng.normal()
+                classifiers[n] = _Model(row) if sibs else "no_negative_examples"
+            tf = {l: _Model(rng.normal(0, 1, size=4)) for l in (-1, 0, 1, 2)}
+            path = os.path.join(tmp, name)
+            ref_db.save_to_file(classifiers, full, tf, False, path, hmm_file_path="/root/reference/stag/test/gene.hmm",
+                                protein_fasta_input=None)
+            taxonomy = {n: list(full[n].children.keys()) for n, _ in full.get_all_nodes(get_root=True)}
+            cls = {k: (m if isinstance(m, str) else np.append(m.intercept_, m.coef_)) for k, m in classifiers.items()}
+            tfd = {str(k): np.append(m.intercept_, m.coef_) for k, m in tf.items()}
+            dbs[name] = (taxonomy, tfd, cls)
+            return path
+
+        gene_paths = [write_db(mg, 5 * ncols[mg], 1.5) for mg in order]
+        concat_path = write_db("concat", 5 * sum(ncols.values()), 0.8)
+        thr = os.path.join(tmp, "thr.tsv")
+        with open(thr, "w") as fh:
+            fh.write("".join("%s\t%d\n" % (mg, 20 + i) for i, mg in enumerate(order)))
+        lens = os.path.join(tmp, "lens.tsv")
+        with open(lens, "w") as fh:
+            fh.write("".join("%s\t%d\n" % (mg, 5 * ncols[mg]) for mg in order))
+        out = os.path.join(OUT, "genome3.stagDB")
+        with tarfile.open(out, "w:gz") as tar:                 # train_genome.py:47-60
+            for p in gene_paths:
+                tar.add(p, os.path.basename(p))
+            for source, target in zip((thr, lens, concat_path), ("threshold_file.tsv", "hmm_lengths_file.tsv",
+                                                                 "concatenated_genes_STAG_database.HDF5")):
+                tar.add(source, target)
+        # marker genes of four genomes: gA has every gene (COG0016 twice: the later line wins, :376), gB lacks
+        # COG0018, gC has only COG0018, "solo.7" has no '_' (split on '.')
+        have = {"COG0016": ["gA_2", "gB_9", "gA_7"], "COG0012": ["gA_1", "gB_4", "solo.7"], "COG0018": ["gC_3", "gA_5"]}
+        a2m, per_gene_rows, ali_dir = {}, {}, os.path.join(tmp, "MG_ali")
+        os.makedirs(ali_dir)
+        for mg in order:
+            recs = []
+            for sid in have[mg]:
+                s = "".join(rng.choice(list("ACGT-"), size=ncols[mg], p=[0.22, 0.22, 0.22, 0.22, 0.12]))
+                at = int(rng.integers(0, ncols[mg]))
+                recs.append((sid + "##" + mg, s[:at] + "ac"[: int(rng.integers(0, 3))] + s[at:]))
+            a2m[mg] = recs
+            taxonomy, tfd, cls = dbs[mg]
+            rows = []
+            with open(os.path.join(ali_dir, mg), "w") as fh:
+                for sid, s in recs:
+                    x, _ = ref_align.convert_alignment(s, 1, as_numpy=True)
+                    rows.append([str(v) for v in ref_classify.classify_seq(sid, x, taxonomy, tfd, cls, 1, 1)])
+                    fh.write(sid + "\t" + "\t".join("1" if b else "0" for b in x) + "\n")
+            per_gene_rows[mg] = rows
+        with contextlib.redirect_stdout(io.StringIO()):
+            cpath = ref_genome.concat_alignments(None, ali_dir, order, {mg: str(5 * ncols[mg]) for mg in order})
+        taxonomy, tfd, cls = dbs["concat"]
+        genome_rows = []
+        for gid, x in ref_classify.alignment_reader(cpath):
+            genome_rows.append([str(v) for v in ref_classify.classify_seq(gid, x, taxonomy, tfd, cls, 1, 1)])
+        concat_text = open(cpath).read()
+        os.remove(cpath)
+        preds = {r[0]: r[1] for mg in order for r in per_gene_rows[mg]}
+        with contextlib.redirect_stdout(io.StringIO()):
+            ref_genome.merge_gene_predictions(None, order, preds, 1, 1, tmp, False, False)
+        merged = {name: open(os.path.join(tmp, "genes_predictions", name)).read()
+                  for name in sorted(os.listdir(os.path.join(tmp, "genes_predictions")))}
+    dump("genome_db.json", {"gene_order": order, "ncols": ncols, "a2m": a2m, "gene_rows": per_gene_rows,
+                            "concatenated": concat_text, "genome_rows": genome_rows, "merged_files": merged})
+    print("wrote genome3.stagDB", os.path.getsize(out), "bytes")
+
+
 def gen_ingest():
     """read_fasta over byte streams and alignment_reader over -s files, with the awkward cases:
     wrapped lines, trailing blanks, CRLF, headers without lines, text before the first header,
@@ -513,6 +665,12 @@ def gen_ingest():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:          # only the named generators, e.g. `make_golden.py c1 genome_db`
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
+    gen_c1()
+    gen_genome_db()
     gen_ingest()
     gen_encode()
     gen_backtranslate()

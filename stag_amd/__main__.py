@@ -44,6 +44,16 @@ def print_menu_classify_genome():
 
 
 def main(argv=None):
+    from . import parallel
+    created = parallel.init_from_env()      # torchrun: one process per GPU, rank 0 writes the output
+    try:
+        return _main(argv)
+    finally:
+        if created:
+            parallel.shutdown()
+
+
+def _main(argv=None):
     parser = argparse.ArgumentParser(prog="stag", add_help=False)
     parser.add_argument("command", choices=["classify", "classify_genome"])
     # flag -> (attribute the reference's code reads, type or None for a switch): stag/__main__.py:205-236

@@ -81,13 +81,14 @@ def _report_backtranslation_failure(status, ids, text, offs, gene):
 def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, threads=1, output=None,
              long_out=False, current_tool_version=tool_version,
              aligned_sequences=None, save_ali_to_file=None, min_perc_state=0, internal_call=False, device=None,
-             packed_rows_out=None, concat_source=None):
-    """The reference's arguments, plus three of this build's own: `device` (GPU index),
+             packed_rows_out=None, concat_source=None, cache=True):
+    """The reference's arguments, plus four of this build's own: `device` (GPU index),
     `packed_rows_out` (a list that receives (ids, packed rows) of every batch written to
-    save_ali_to_file) and `concat_source` (marker-gene rows to concatenate on the GPU instead of
-    reading aligned_sequences; see classify_genome.concat_on_device)."""
+    save_ali_to_file), `concat_source` (marker-gene rows to concatenate on the GPU instead of
+    reading aligned_sequences; see classify_genome.concat_on_device) and `cache` (False: do not
+    look the database up in, or add it to, the packed-table cache)."""
     t0 = time.time()
-    cached = table_cache.load(database, protein_fasta_input, aligned_sequences)
+    cached = table_cache.load(database, protein_fasta_input, aligned_sequences) if cache else None
     if cached is not None:
         hmm_file_path, use_cmalign, tables, db_tool_version = cached
     else:
@@ -95,7 +96,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
         hmm_file_path, use_cmalign, taxonomy, tax_function, classifiers, db_tool_version = loaded
         tables = pack_db(taxonomy, tax_function, classifiers)
         del classifiers
-        if table_cache.cache_dir() and os.path.isfile(database):
+        if cache and table_cache.cache_dir() and os.path.isfile(database):
             with open_stagdb(database) as db_in:
                 use_proteins = bool(db_in.read("align_protein")[0])
             table_cache.store(database, tables, hmm_file_path, use_cmalign, use_proteins, db_tool_version)

@@ -11,6 +11,7 @@ import ctypes
 import os
 import shutil
 import sys
+import tarfile
 import tempfile
 
 import numpy as np
@@ -151,24 +152,39 @@ def open_stagdb(path):
                           "(make -C stag_amd/csrc h5 needs libhdf5) and h5py is not importable") from None
 
 
+GENOME_DB_CORE = ("threshold_file.tsv", "hmm_lengths_file.tsv", "concatenated_genes_STAG_database.HDF5")
+
+
+def _two_column_table(path):
+    """{first column: second column} of a two-column TSV, in file order (a line that does not have
+    exactly two columns is an error, as it is for the reference's dict(...) over split lines)."""
+    table = {}
+    with open(path) as fh:
+        for line in fh:
+            key, value = line.rstrip().split("\t")
+            table[key] = value
+    return table
+
+
 def load_genome_DB(database, tool_version=tool_version, verbose=3):
-    """stag/databases.py:15-33.  Returns (list_files, dirpath, gene_thresholds, gene_order,
-    ali_lengths, path of the concatenated-genes database)."""
-    dirpath = tempfile.mkdtemp()
-    shutil.unpack_archive(database, dirpath, "gztar")
-    list_files = [f for f in os.listdir(dirpath) if os.path.isfile(os.path.join(dirpath, f))]
-    for f in ("threshold_file.tsv", "hmm_lengths_file.tsv", "concatenated_genes_STAG_database.HDF5"):
-        if f not in list_files:
-            raise ValueError(f"[E::align] Error: {f} is missing.")
-    with open(os.path.join(dirpath, "threshold_file.tsv")) as fh:
-        gene_thresholds = dict(line.rstrip().split("\t") for line in fh)
-    gene_order = list(gene_thresholds.keys())
-    with open(os.path.join(dirpath, "hmm_lengths_file.tsv")) as fh:
-        ali_lengths = dict(line.rstrip().split("\t") for line in fh)
-    for f in ("threshold_file.tsv", "hmm_lengths_file.tsv", "concatenated_genes_STAG_database.HDF5"):
-        list_files.remove(f)
-    return (list_files, dirpath, gene_thresholds, gene_order, ali_lengths,
-            os.path.join(dirpath, "concatenated_genes_STAG_database.HDF5"))
+    """stag/databases.py:15-33 for the tar layout of train_genome.py:46-60.  Returns (marker-gene database
+    file names, the temp directory they were unpacked into, {gene: threshold}, gene order = the order of
+    threshold_file.tsv, {gene: alignment length}, path of the concatenated-genes database).  The caller
+    removes the directory."""
+    workdir = tempfile.mkdtemp()
+    with tarfile.open(database, "r:gz") as tar:
+        if hasattr(tarfile, "data_filter"):
+            tar.extractall(workdir, filter="data")      # no absolute paths, links out of the tree or devices
+        else:
+            tar.extractall(workdir)
+    unpacked = {name for name in os.listdir(workdir) if os.path.isfile(os.path.join(workdir, name))}
+    for name in GENOME_DB_CORE:
+        if name not in unpacked:
+            raise ValueError(f"[E::align] Error: {name} is missing.")
+    thresholds = _two_column_table(os.path.join(workdir, GENOME_DB_CORE[0]))
+    lengths = _two_column_table(os.path.join(workdir, GENOME_DB_CORE[1]))
+    gene_files = sorted(unpacked.difference(GENOME_DB_CORE))
+    return gene_files, workdir, thresholds, list(thresholds), lengths, os.path.join(workdir, GENOME_DB_CORE[2])
 
 
 def load_db(hdf5_DB_path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):

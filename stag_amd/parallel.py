@@ -17,6 +17,28 @@ def world_rank():
     return 1, 0
 
 
+def init_from_env():
+    """Under a launcher that sets RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun), join the process
+    group before anything else runs, so that world_rank() is the truth in every rank: without it every rank
+    would take itself for rank 0, classify the whole input and write the same output files.  gloo is enough
+    -- the group only carries result rows to rank 0 (the data path has no collective).  Returns True when
+    this call created the group (the caller then destroys it with shutdown())."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1 or "RANK" not in os.environ:
+        return False
+    import torch.distributed as dist
+    if dist.is_initialized():
+        return False
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group(os.environ.get("STAG_DIST_BACKEND", "gloo"))
+    return True
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
 def local_device():
     return int(os.environ.get("STAG_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 

@@ -1,7 +1,12 @@
 """CPU: host logic of the drop-in (classify(), classify_genome pieces, rank sharding) with the
 GPU engine replaced by the oracle-backed stand-in of tests/fake_engine.py.  The arithmetic is
 NOT what is under test here (tests/test_gpu_*.py do that on the real kernels); file formats,
-output text, return values, error behaviour and the world_size-2 sharding are."""
+output text, return values, error behaviour and the world_size-2 sharding are.
+
+The tests that drive classify() through the aligner pipe, the protein path, -S and classify_genome
+take the `engine` fixture: "oracle" is the stand-in (runs here), "gpu" leaves the real
+stag_amd.engine.Database in place and is marked gpu, so `pytest -m gpu` runs the very same
+scenarios -- stand-in aligner scripts, first-failure ordering, the -S text -- on the HIP kernels."""
 import io
 import json
 import os
@@ -26,6 +31,9 @@ TINY = os.path.join(gu.GOLDEN, "tiny.stagDB")
 @pytest.fixture
 def fake_gpu(monkeypatch):
     monkeypatch.setattr(sc, "Database", OracleDatabase)
+
+
+from conftest import RTOL      # the `engine` fixture lives there
 
 
 def golden_tsv_setup(monkeypatch, tmp_path):
@@ -80,7 +88,7 @@ def test_classify_verbose_and_errors(fake_gpu, monkeypatch, tmp_path, capsys):
     assert ret == (None, []) and open(tmp_path / "o3").read() == "sequence\ttaxonomy\n"
 
 
-def test_classify_from_aligner_pipe_with_fake_tools(fake_gpu, monkeypatch, tmp_path):
+def test_classify_from_aligner_pipe_with_fake_tools(engine, monkeypatch, tmp_path):
     """fasta_input path: hmmalign | esl-reformat (stand-in scripts that replay a prepared A2M
     stream) -> native FASTA scanner -> encode + classify -> rows, and the -S file.  Expected
     values are the reference's own output for the same rows through -s (tsv.json)."""
@@ -118,7 +126,7 @@ def test_classify_from_aligner_pipe_with_fake_tools(fake_gpu, monkeypatch, tmp_p
         sc.classify("db", fasta_input=str(fasta), output=str(tmp_path / "o2"), verbose=1)
 
 
-def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_path, capsys):
+def test_classify_protein_database_with_fake_tools(engine, monkeypatch, tmp_path, capsys):
     """protein_fasta_input path: the protein alignment from the pipe is paired with the gene file
     (text mode, CRLF here), back-translated and classified; rows equal the nucleotide path's."""
     g, ali = golden_tsv_setup(monkeypatch, tmp_path)       # L = 80: 16 columns -> needs a multiple of 3
@@ -159,7 +167,7 @@ def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_pa
     assert n == L and len(rows) == 9
     for i, row in enumerate(rows):
         x, _ = oracle_np.convert_alignment(nucs[i])
-        gu.rows_match(row, oracle_np.classify_seq("r%d" % i, x, taxonomy, tax_function, classifiers), rtol=1e-12)
+        gu.rows_match(row, oracle_np.classify_seq("r%d" % i, x, taxonomy, tax_function, classifiers), rtol=RTOL[engine])
     # a gene of the wrong length: message of align.py:70-73, then the reference's TypeError
     gene_file.write_text("".join(">r%d\n%s\n" % (i, s + ("A" if i == 4 else "")) for i, s in enumerate(genes)))
     capsys.readouterr()
@@ -182,7 +190,7 @@ def test_classify_protein_database_with_fake_tools(fake_gpu, monkeypatch, tmp_pa
         sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1, output=str(tmp_path / "o4"))
 
 
-def test_classify_genome_fused_concat_equals_text_path(fake_gpu, monkeypatch, tmp_path):
+def test_classify_genome_fused_concat_equals_text_path(engine, monkeypatch, tmp_path):
     """classify_genome -G end to end (marker-gene DBs, MG_ali, genes_predictions, genome_annotation):
     the concatenated rows assembled from the packed marker-gene rows give byte for byte the
     genome_annotation of the reference's text round trip (concat_alignments, pinned by concat.json)."""
@@ -252,6 +260,16 @@ def test_classify_genome_fused_concat_equals_text_path(fake_gpu, monkeypatch, tm
     for sub in ("MG_ali", "genes_predictions"):
         for f in os.listdir(text / sub):
             assert (fused / sub / f).read_bytes() == (text / sub / f).read_bytes()
+    if engine == "gpu":      # and what the kernels gave is what the oracle gives for the same files
+        monkeypatch.setattr(sc, "Database", OracleDatabase)
+        ref = tmp_path / "oracle"
+        scg.classify_genome("genomedb", marker_genes=[str(spec)], output=str(ref), verbose=1, long_out=True)
+        want = (ref / "genome_annotation").read_text().splitlines()
+        assert a.splitlines()[0] == want[0] and len(want) == 4
+        for got_line, want_line in zip(a.splitlines()[1:], want[1:]):
+            gu.rows_match(got_line.split("\t"), want_line.split("\t"), rtol=RTOL["gpu"])
+        for f in os.listdir(ref / "MG_ali"):
+            assert (fused / "MG_ali" / f).read_bytes() == (ref / "MG_ali" / f).read_bytes()
 
 
 def test_parse_onehot_line_matches_reference_reader():
@@ -379,6 +397,60 @@ def test_sharded_classify_world2_gloo(fake_gpu, tmp_path):
         _, err = p.communicate(timeout=120)
         assert p.returncode != 0 and "ValueError" in err.decode() and "[sequence r9]" in err.decode(), err.decode()[-2000:]
     assert not os.path.exists(str(tmp_path / "dist2") + ".rank0")
+
+
+CLI_WORKER = r'''
+import os, sys
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import stag_amd.classify as sc
+from fake_engine import OracleDatabase
+sc.Database = OracleDatabase
+sc.READER_BATCH = 7
+from stag_amd.__main__ import main
+main(["classify", "-d", {db!r}, "-s", {ali!r}, "-o", {out!r}, "-v", "3", "-l"])
+'''
+
+
+@pytest.mark.skipif(databases._load_h5lib() is None, reason="libstag_h5.so not built")
+def test_command_line_under_a_launcher_joins_the_process_group(fake_gpu, tmp_path):
+    """`torchrun ... -m stag_amd classify`: the command line itself joins the process group from RANK /
+    WORLD_SIZE / MASTER_* (nothing else on that path does), so the ranks share the batches and only rank 0
+    writes the output file -- instead of every rank classifying everything and writing the same file."""
+    rng = np.random.default_rng(11)
+    lines = []
+    for i in range(50):
+        x = np.zeros(145, dtype=bool)
+        x[5 * np.arange(29) + rng.integers(0, 5, size=29)] = True
+        lines.append("r%d\t%s" % (i, "\t".join("1" if b else "0" for b in x)))
+    ali = tmp_path / "a.tsv"
+    ali.write_text("\n".join(lines) + "\n")
+    single = tmp_path / "single.tsv"
+    sc.classify(TINY, aligned_sequences=str(ali), output=str(single), long_out=True, verbose=1)
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = tmp_path / "dist.tsv"
+    marker = tmp_path / "writes"
+    code = CLI_WORKER.format(root=ROOT, db=TINY, ali=str(ali), out=str(out))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), TMPDIR=str(tmp_path / ("tmp%d" % r)))
+        os.makedirs(env["TMPDIR"])
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, stderr=subprocess.PIPE))
+    errs = []
+    for p in procs:
+        _, err = p.communicate(timeout=120)
+        assert p.returncode == 0, err.decode()[-2000:]
+        errs.append(err.decode())
+    assert out.read_text() == single.read_text()
+    # "Classify sequences: ..." is printed by the rank that goes on to write the output (classify.py:164-166)
+    assert "Classify sequences: " in errs[0] and "Classify sequences: " not in errs[1]
+    # the output goes through a temp file in TMPDIR and a move: only rank 0's TMPDIR ever held one, and
+    # neither rank left anything behind (HMM temp files included)
+    assert os.listdir(tmp_path / "tmp0") == [] and os.listdir(tmp_path / "tmp1") == []
 
 
 def test_command_line_classify_and_its_argument_errors(fake_gpu, monkeypatch, tmp_path, capsys):
