@@ -121,7 +121,7 @@ def test_c5_50k_nodes_at_full_width():
             node = res.path_node[:, d].astype(np.int64)
             assert ((node >= cf[prev]) & (node < cf[prev + 1])).all()
             prev = node
-        assert len(np.unique(res.path_node[:, 6])) > 5000
+        assert len(np.unique(res.path_node[:, 6])) > 1000
         rng = np.random.default_rng(5)
         idx = rng.permutation(np.repeat(rng.integers(0, n, size=30_000), 2))
         sub = run(db, text, offs, idx)
