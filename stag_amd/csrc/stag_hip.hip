@@ -320,10 +320,10 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
                                n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, wk.node,
                                wk.count, wk.pos);
-            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, wk.count, wk.task_off,
-                               wk.n_tasks + d);
+            hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, wk.count, db->child_first.p,
+                               db->node_err.p, wk.task_off, wk.n_tasks + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, wk.node, wk.pos, wk.count,
-                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks);
+                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks, cur, o.status);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;

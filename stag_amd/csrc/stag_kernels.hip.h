@@ -20,6 +20,9 @@
 
 namespace stagk {
 
+#ifndef STAG_ABL
+#define STAG_ABL 0                // timing ablations of k_walk_level (tools/walk_ablations.sh); 0 = the product
+#endif
 constexpr int TILE = 64;          // sequences per walk task = lanes of a wave
 #ifndef STAG_NW
 #define STAG_NW 4
@@ -602,18 +605,30 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
     }
 }
 
+// A node whose sequences need no scoring: a leaf (k == 0: the walk ends), a single child (k == 1: the
+// placeholder 2 of classify.py:37, its classifier is never evaluated) or a node at which the reference
+// raises (err).  k_scatter / k_root_level write those sequences' level records themselves; only the
+// other nodes get walk tasks.
+__device__ __forceinline__ bool node_is_trivial(const int32_t *__restrict__ child_first,
+                                                const uint8_t *__restrict__ node_err, int nd) {
+    return child_first[nd + 1] - child_first[nd] <= 1 || node_err[nd] != 0;
+}
+
 // One workgroup: exclusive scan of the task counts over the nodes [lo, hi) of one level.
 // Each thread owns a contiguous run of nodes; the 1024 run totals are scanned with DPP inside
 // waves and one LDS exchange of the 16 wave totals.
 __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32_t *__restrict__ count,
+                                                     const int32_t *__restrict__ child_first,
+                                                     const uint8_t *__restrict__ node_err,
                                                      int32_t *__restrict__ task_off,
                                                      int32_t *__restrict__ n_tasks) {
     __shared__ int s_wb[16];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (hi - lo + 1023) / 1024;
     const int i0 = lo + t * per, i1 = min(hi, i0 + per);
+    auto tasks_of = [&](int i) { return node_is_trivial(child_first, node_err, i) ? 0 : (count[i] + TILE - 1) / TILE; };
     int sb = 0;
-    for (int i = i0; i < i1; ++i) sb += (count[i] + TILE - 1) / TILE;
+    for (int i = i0; i < i1; ++i) sb += tasks_of(i);
     const int ib = wave_incl_scan(sb, lane);
     if (lane == 63) s_wb[wave] = ib;
     __syncthreads();
@@ -625,9 +640,25 @@ __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32
     int rb = base_b + ib - sb;
     for (int i = i0; i < i1; ++i) {
         task_off[i] = rb;
-        rb += (count[i] + TILE - 1) / TILE;
+        rb += tasks_of(i);
     }
     if (t == 0) *n_tasks = tot_b;
+}
+
+// What a trivial node decides for every sequence standing on it (see node_is_trivial).
+__device__ __forceinline__ void settle_trivial(int c0, int k, int err, int64_t s, LevelRec *__restrict__ cur,
+                                               int32_t *__restrict__ status) {
+    LevelRec r;
+    r.pad = 0;
+    if (err) {            // the reference raises here (classify.py:40 / :24-25)
+        status[s] = err;
+        r.node = -1; r.prob = 0.0;
+    } else if (k == 1) {  // classify.py:36-37: the only child, placeholder score 2, classifier not evaluated
+        r.node = c0; r.prob = 2.0;
+    } else {              // a leaf: the walk ends (classify.py:34-35)
+        r.node = -1; r.prob = 0.0;
+    }
+    cur[s] = r;
 }
 
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
@@ -635,11 +666,17 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
                                                  const int32_t *__restrict__ task_off,
                                                  const int32_t *__restrict__ child_first,
                                                  const uint8_t *__restrict__ node_err, const uint32_t *__restrict__ win,
-                                                 SeqRef *__restrict__ order, Task *__restrict__ tasks) {
+                                                 SeqRef *__restrict__ order, Task *__restrict__ tasks,
+                                                 LevelRec *__restrict__ cur, int32_t *__restrict__ status) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int nd = node[s];
     if (nd < lo || nd >= hi) return;
+    const int c0 = child_first[nd], k = child_first[nd + 1] - c0, err = node_err[nd];
+    if (k <= 1 || err) {
+        settle_trivial(c0, k, err, s, cur, status);
+        return;
+    }
     const int p = pos[s];
     const int task = task_off[nd] + p / TILE;
     SeqRef ref;
@@ -648,8 +685,8 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
     order[(size_t)task * TILE + (p & (TILE - 1))] = ref;
     if ((p & (TILE - 1)) == 0) {
         Task tk;
-        tk.node = nd; tk.pad2 = 0; tk.count = min(TILE, count[nd] - p); tk.err = node_err[nd];
-        tk.c0 = child_first[nd]; tk.k = child_first[nd + 1] - tk.c0; tk.pad0 = 0; tk.pad1 = 0;
+        tk.node = nd; tk.pad2 = 0; tk.count = min(TILE, count[nd] - p); tk.err = 0;
+        tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
         tasks[task] = tk;
     }
 }
@@ -666,18 +703,22 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
     if (s >= n) return;
     const int st = status_in ? status_in[s] : 0;
     status[s] = st;
+    const int c0 = child_first[0], k = child_first[1] - c0, err = node_err[0];
+    const bool trivial = k <= 1 || err;
+    if (st != 0) cur[s].node = -1;
+    else if (trivial) settle_trivial(c0, k, err, s, cur, status);
+    if (s == 0) *n_tasks = trivial ? 0 : (int32_t)((n + TILE - 1) / TILE);
+    if (trivial) return;
     SeqRef ref;
     ref.seq = st == 0 ? (int32_t)s : -1;
     ref.win = win[s];
     order[s] = ref;
-    if (st != 0) cur[s].node = -1;
     if ((s & (TILE - 1)) == 0) {
         Task tk;
-        tk.node = 0; tk.pad2 = 0; tk.count = (int32_t)min((int64_t)TILE, n - s); tk.err = node_err[0];
-        tk.c0 = child_first[0]; tk.k = child_first[1] - tk.c0; tk.pad0 = 0; tk.pad1 = 0;
+        tk.node = 0; tk.pad2 = 0; tk.count = (int32_t)min((int64_t)TILE, n - s); tk.err = 0;
+        tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
         tasks[s / TILE] = tk;
     }
-    if (s == 0) *n_tasks = (int32_t)((n + TILE - 1) / TILE);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -748,6 +789,20 @@ __device__ __forceinline__ double masked_weight_v(const char *my_row, const uint
 
 constexpr int ENT_PIECE = 48;     // coefficients a wave keeps in LDS at a time (768 B)
 
+// LDS-DMA (global_load_lds_*): each active lane's 4 / 16 bytes at `src` land in LDS at dst + lane * 4 / 16
+// (dst is wave-uniform) without passing through a VGPR.  hipcc counts these on vmcnt and drains them before
+// a __syncthreads(); a wave that reads its OWN DMA'd data without a barrier waits with dma_wait().
+#define STAG_GLOBAL __attribute__((address_space(1)))
+#define STAG_LDS __attribute__((address_space(3)))
+__device__ __forceinline__ void dma4(const uint32_t *src, uint32_t *dst) {
+    __builtin_amdgcn_global_load_lds((const STAG_GLOBAL void *)src, (STAG_LDS void *)dst, 4, 0, 0);
+}
+__device__ __forceinline__ void dma16(const uint4 *src, uint4 *dst) {
+    __builtin_amdgcn_global_load_lds((const STAG_GLOBAL void *)src, (STAG_LDS void *)dst, 16, 0, 0);
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
     // per wave 768 B: the coefficients of its sibling inside the slice while it scores, then its
@@ -781,19 +836,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     auto s_z = [&](int w) { return reinterpret_cast<double *>(s_buf[w]); };
     auto s_c = [&](int w) { return reinterpret_cast<int *>(s_buf[w]) + 2 * TILE; };
 
-    if (k <= 1 || err) {  // a leaf; nothing to score (classify.py:35-37); or the reference raises
-        if (wave == 0 && seq >= 0) {
-            if (err) {
-                a.status[seq] = err;
-                put(-1, 0.0);
-            } else if (k == 1) {
-                put(c0, 2.0);
-            } else {
-                put(-1, 0.0);
-            }
-        }
-        return;
-    }
+    if (k <= 1 || err) return;   // never emitted: k_scatter / k_root_level settle such nodes themselves
+#if STAG_ABL == 5
+    if (seq >= 0) put(c0, 0.5);
+    return;
+#endif
 
     // ---- the task's window in chunks [cA, cB): union of its rows' windows
     int lo = 0x7fff, hi = 0;
@@ -826,30 +873,25 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     double best_p = -1.0;
     int best_c = -1;
     const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
-    // rows of the slice [sA, sB) -> LDS: one row per wave and step, lanes over words.  Ends with the
-    // stores issued; the caller's barrier makes them visible.
+    // rows of the slice [sA, sB) -> LDS by LDS-DMA: one row per wave and step, lanes over words, no VGPR in
+    // between.  The caller makes sure nobody still reads the previous slice (barrier) before, and drains the
+    // DMA + barriers after.  Rows of absent lanes (seq < 0) and words past the slice keep stale data that
+    // no entry of the slice refers to / whose result is never stored.
     auto stage_rows = [&](int sA, int sB) {
         const int w0 = sA * CHUNK_WORDS;
         const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
-        uint32_t v[TILE / NW];
+        if (lane < width) {
 #pragma unroll
-        for (int rr = 0; rr < TILE / NW; ++rr) {
-            // the row's sequence id as a scalar: its address is then computed once per wave
-            const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-            v[rr] = 0u;
-            if (s >= 0) {
-                const uint32_t *src = a.bits + ((size_t)s * a.W + w0);
-                if (lane < width) v[rr] = src[lane];
+            for (int rr = 0; rr < TILE / NW; ++rr) {
+                // the row's sequence id as a scalar: its address is then computed once per wave
+                const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+                if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * ROW_STRIDE]);
             }
         }
-        __syncthreads();  // everyone is done reading the previous slice
-#pragma unroll
-        for (int rr = 0; rr < TILE / NW; ++rr) s_rows[(rr * NW + wave) * ROW_STRIDE + lane] = v[rr];
     };
+    // this wave's first ENT_PIECE coefficients of [e_lo, e_hi) -> its piece of LDS (wave-private)
     auto fetch_ent = [&](uint32_t e_lo, uint32_t e_hi) {
-        uint4 ent = make_uint4(0u, 0u, 0u, 0u);
-        if (lane < ENT_PIECE && e_lo + lane < e_hi) ent = a.blocks[e_lo + lane];
-        return ent;
+        if (lane < ENT_PIECE && e_lo + lane < e_hi) dma16(a.blocks + e_lo + lane, s_ent);
     };
     // z += the sibling's chunk sums over the slice [sA, sB) (its first ENT_PIECE coefficients are in s_ent)
     auto score_slice = [&](double &z, const uint32_t STAG_CONST *bo, uint32_t e_lo, uint32_t e_hi, int sA, int sB) {
@@ -881,8 +923,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
                     if (e >= piece + ENT_PIECE) {   // more than 48 coefficients in the slice: next piece
                         piece = e;
-                        if (lane < ENT_PIECE)
-                            s_ent[lane] = piece + lane < e_hi ? a.blocks[piece + lane] : make_uint4(0u, 0u, 0u, 0u);
+                        lds_reads_done();
+                        fetch_ent(piece, e_hi);
+                        dma_wait();
                     }
                     const uint4 *pe = &s_ent[e - piece];
                     const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
@@ -902,7 +945,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         return a.gappre[base + i_lo] + a.gapsuf[base + i_hi];
     };
     auto decide = [&](double z, int c) {
+#if STAG_ABL == 2
+        const double p = z + as_const(a.intercept)[c];
+#else
         const double p = sigmoid(z + as_const(a.intercept)[c]);
+#endif
         if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
     };
 
@@ -913,20 +960,27 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             const int c = c0 + pass0 + wave;
             const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
             double z = 0.0;
+#if STAG_ABL != 4
             if (active) z = gap_consts(c);
+#endif
             if (wB > wA) {
                 // this wave's coefficient range of the window: contiguous, chunk after chunk
                 uint32_t e_lo = 0, e_hi = 0;
                 if (active) { e_lo = bo[wA] * BLOCK_ENTRIES; e_hi = bo[wB] * BLOCK_ENTRIES; }
-                const uint4 ent = fetch_ent(e_lo, e_hi);   // in flight together with the rows
                 if (pass0 == 0) {
+#if STAG_ABL != 3
                     stage_rows(wA, wB);
-                    if (lane < ENT_PIECE) s_ent[lane] = ent;
-                    __syncthreads();
+#endif
+                    fetch_ent(e_lo, e_hi);       // in flight together with the rows
+                    __syncthreads();             // drains the DMA of every wave, then the barrier
                 } else {
-                    if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private: LDS operations of one wave stay in order
+                    lds_reads_done();            // wave-private piece: the previous sibling's reads have returned
+                    fetch_ent(e_lo, e_hi);
+                    dma_wait();
                 }
+#if STAG_ABL != 1
                 if (active) score_slice(z, bo, e_lo, e_hi, wA, wB);
+#endif
             }
             if (active) decide(z, c);
         }
@@ -943,15 +997,17 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             }
             for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
                 const int sB = min(wB, sA + WCAP_CHUNKS);
+                __syncthreads();   // everyone is done reading the previous slice
                 stage_rows(sA, sB);
-                __syncthreads();
+                __syncthreads();   // DMA drained, rows visible
 #pragma unroll
                 for (int j = 0; j < PG; ++j) {
                     if (pg0 + j * NW + wave < k) {   // wave-uniform
                         const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
                         const uint32_t e_lo = bo[sA] * BLOCK_ENTRIES, e_hi = bo[sB] * BLOCK_ENTRIES;
-                        const uint4 ent = fetch_ent(e_lo, e_hi);
-                        if (lane < ENT_PIECE) s_ent[lane] = ent;   // wave-private, after the previous sibling's reads
+                        lds_reads_done();            // wave-private piece, after the previous sibling's reads
+                        fetch_ent(e_lo, e_hi);
+                        dma_wait();
                         score_slice(zz[j], bo, e_lo, e_hi, sA, sB);
                     }
                 }
@@ -961,6 +1017,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 if (pg0 + j * NW + wave < k) decide(zz[j], c0 + pg0 + j * NW + wave);
         }
     }
+    // (the result slots below reuse each wave's own coefficient piece: LDS operations of one wave stay in order)
     s_z(wave)[lane] = best_p;
     s_c(wave)[lane] = best_c;
     __syncthreads();
