@@ -129,7 +129,12 @@ int stag_classify_bits_dev(stag_db_t *db, const uint32_t *d_bits, int64_t n, con
                            const stag_results_t *d_out, void *stream);
 
 /* Encode + classify without the rows leaving the GPU.  bits_out (may be NULL) receives the
- * packed rows (for -S, classify.py:160-162). */
+ * packed rows (for -S, classify.py:160-162).
+ * The host form is a pipeline: the batch is cut into sub-batches of 65,536 records whose text
+ * goes up on one stream while the previous sub-batch is computed on a second and the results of the one before
+ * come down on a third, straight into the caller's arrays.  The copies overlap only if the caller's buffers
+ * are page-locked -- stag_host_alloc gives such memory (text, offs, every output array); with pageable buffers
+ * the call is still correct, the HIP runtime then stages each copy itself. */
 int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n,
                       double min_perc_state, const stag_results_t *out, uint32_t *bits_out,
                       int32_t *n_char_out);
@@ -191,6 +196,12 @@ int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len
  * out must hold 3*prot_len bytes.  *out_len = -1 reproduces the reference's `return None`. */
 int stag_backtranslate(const char *prot, int64_t prot_len, const char *gene, int64_t gene_len,
                        int32_t check_length, char *out, int64_t *out_len);
+
+/* Page-locked host memory for the buffers of the host entry points (hipHostMalloc / hipHostFree): what the
+ * ingestion side parses text into and results come back in, so that the pipeline of stag_classify_a2m runs its
+ * copies as DMA beside the kernels.  No counterpart in the reference (it has no device).  NULL on failure. */
+void *stag_host_alloc(int64_t bytes);
+void stag_host_free(void *p);
 
 /*
  * Per-kernel device timing for bench.py: when enabled every launch on this handle is

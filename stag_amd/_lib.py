@@ -65,6 +65,8 @@ EXPORTS = {
                                                      ctypes.c_double, ctypes.POINTER(Results), c_p]),
     "stag_classify_concat": (ctypes.c_int, [c_p, ctypes.c_int32, c_p, c_p, c_p, c_p, c_p, ctypes.c_int64,
                                             ctypes.POINTER(Results), c_p]),
+    "stag_host_alloc": (c_p, [ctypes.c_int64]),
+    "stag_host_free": (None, [c_p]),
     "stag_profile_enable": (ctypes.c_int, [c_p, ctypes.c_int32]),
     "stag_profile_read": (ctypes.c_int, [c_p, c_p, c_p]),
 }
@@ -98,7 +100,41 @@ def ptr(a):
     return None if a is None else a.ctypes.data_as(c_p)
 
 
+def kernel_source_sha1():
+    """Hash of the sources libstag_hip.so is built from (they travel with the library): what a committed
+    profile is stamped with, so that numbers measured on other kernels are not mistaken for this build's."""
+    import hashlib
+    h = hashlib.sha1()
+    for name in ("stag_kernels.hip.h", "stag_hip.hip"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def device_count():
     n = ctypes.c_int32(0)
     lib().stag_device_count(ctypes.byref(n))
     return n.value
+
+
+class PinnedArray:
+    """A NumPy array over page-locked host memory from stag_host_alloc: buffers of this kind let the host
+    entry points copy by DMA beside the kernels.  .a is the array; the memory lives as long as this object."""
+
+    def __init__(self, shape, dtype):
+        shape = (shape,) if np.isscalar(shape) else tuple(shape)
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().stag_host_alloc(max(self.nbytes, 16))
+        if not self._p:
+            raise StagError("stag_host_alloc(%d) failed: %s" % (self.nbytes, lib().stag_last_error().decode()))
+        buf = (ctypes.c_uint8 * max(self.nbytes, 16)).from_address(self._p)
+        self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def __del__(self):
+        try:
+            if self._p:
+                self.a = None
+                lib().stag_host_free(self._p)
+                self._p = None
+        except Exception:
+            pass

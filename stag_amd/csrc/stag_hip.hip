@@ -133,6 +133,19 @@ struct stag_db {
     // results (used when the caller passes NULL or host pointers)
     DevBuf<int32_t> r_path_node, r_path_len, r_lead, r_selected, r_n_aligned, r_status;
     DevBuf<double> r_path_prob, r_level_prob;
+    // host pipeline of stag_classify_a2m (pipe_setup): two slots of device text / offsets / results, a copy-in,
+    // a compute and a copy-out stream.  Slot j % 2 holds sub-batch j: its text goes up while sub-batch j - 1 is
+    // computed and the results of j - 2 come down.
+    struct Slot {
+        DevBuf<uint8_t> text;
+        DevBuf<int64_t> offs;
+        DevBuf<int32_t> path_node, path_len, lead, selected, n_aligned, status, n_char;
+        DevBuf<double> path_prob, level_prob;
+        DevBuf<uint32_t> bits;
+        hipEvent_t up = nullptr, done = nullptr, down = nullptr;   // H2D finished / kernels finished / D2H finished
+        bool used = false;
+    } slot[2];
+    hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     // profiling
     bool prof = false;
     std::vector<ProfRec> recs;
@@ -147,6 +160,15 @@ struct stag_db {
         r_n_aligned.release(); r_status.release(); r_path_prob.release(); r_level_prob.release();
         for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         recs.clear();
+        for (auto &sl : slot) {
+            sl.text.release(); sl.offs.release(); sl.path_node.release(); sl.path_len.release(); sl.lead.release();
+            sl.selected.release(); sl.n_aligned.release(); sl.status.release(); sl.n_char.release();
+            sl.path_prob.release(); sl.level_prob.release(); sl.bits.release();
+            for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down})
+                if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+        }
+        for (hipStream_t *st : {&s_up, &s_run, &s_down})
+            if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
     }
 };
 
@@ -352,6 +374,24 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
     return launch_check("k_rankcut");
 }
 
+// Host record offsets must be non-negative and non-decreasing: an interior offset outside its neighbours would
+// send the encode kernel before or past the text buffer.
+int check_offsets(const int64_t *offs, int64_t n, const char *what) {
+    if (offs[0] < 0) return fail(STAG_E_INVALID, "%s[0] is negative", what);
+    for (int64_t i = 0; i < n; ++i)
+        if (offs[i + 1] < offs[i])
+            return fail(STAG_E_INVALID, "%s must be non-decreasing (%s[%lld] = %lld > %s[%lld] = %lld)", what, what,
+                        (long long)i, (long long)offs[i], what, (long long)(i + 1), (long long)offs[i + 1]);
+    return STAG_OK;
+}
+
+// Records per sub-batch of the host pipeline (STAG_PIPE_RECORDS overrides it for tests).
+int64_t pipe_records() {
+    const char *e = getenv("STAG_PIPE_RECORDS");
+    const long long v = e ? atoll(e) : 0;
+    return v > 0 ? v : 65536;
+}
+
 template <typename T>
 int d2h(T *host, const T *dev, size_t count, hipStream_t st) {
     if (!host || count == 0) return STAG_OK;
@@ -399,6 +439,8 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     if (!t->child_first || !t->row_kind || !t->intercept || !t->row_off || (t->n_keys > 0 && !t->tf))
         return fail(STAG_E_INVALID, "null table pointer");
     if (t->n_keys < 0 || t->n_tf < 0) return fail(STAG_E_INVALID, "negative rank-cut shape");
+    if (t->row_off[t->n_nodes] > 0 && (!t->row_feat || !t->row_w))
+        return fail(STAG_E_INVALID, "row_off announces %lld coefficients but row_feat / row_w is null", (long long)t->row_off[t->n_nodes]);
     const int n = t->n_nodes;
     if (t->child_first[n] != n || (n > 1 && t->child_first[0] != 1) || (n == 1 && t->child_first[0] != 1))
         return fail(STAG_E_INVALID, "child_first is not a breadth-first numbering (child_first[0]=%d, child_first[n]=%d, n=%d)",
@@ -572,8 +614,8 @@ int stag_encode_a2m(int32_t device, int32_t n_features, const char *text, const 
     int rc = check_device(device);
     if (rc || n == 0) return rc;
     const int W = stag_words_per_row(n_features);
+    if ((rc = check_offsets(offs, n, "offs"))) return rc;
     const int64_t text_bytes = offs[n];
-    if (offs[0] < 0 || text_bytes < offs[0]) return fail(STAG_E_INVALID, "offs must be non-decreasing");
     DevBuf<uint8_t> d_text;
     DevBuf<int64_t> d_offs;
     DevBuf<uint32_t> d_bits;
@@ -698,22 +740,98 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
                       const stag_results_t *out, uint32_t *bits_out, int32_t *n_char_out) {
     if (!db || n < 0 || !out || (n > 0 && (!text || !offs || !out->status))) return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
-    HIP_TRY(hipSetDevice(db->device));
-    const int64_t text_bytes = offs[n];
-    if (offs[0] < 0 || text_bytes < offs[0]) return fail(STAG_E_INVALID, "offs must be non-decreasing");
     int rc;
-    if ((rc = stag_db_reserve(db, n, std::max<int64_t>(text_bytes, 1))) || (rc = db->text.reserve(text_bytes + 16)) ||
-        (rc = db->offs.reserve(n + 1)))
-        return rc;
-    HIP_TRY(hipMemcpy(db->text.p, text, text_bytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(db->offs.p, offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    if ((rc = stag_classify_a2m_dev(db, (const char *)db->text.p, (text_bytes + 15) / 16 * 16, db->offs.p, n, min_perc_state, nullptr,
-                                    nullptr)))
-        return rc;
-    if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;
-    if (bits_out) HIP_TRY(hipMemcpy(bits_out, db->bits.p, (size_t)n * db->W * 4, hipMemcpyDeviceToHost));
-    if (n_char_out) HIP_TRY(hipMemcpy(n_char_out, db->enc_n_char.p, n * 4, hipMemcpyDeviceToHost));
-    return STAG_OK;
+    if ((rc = check_offsets(offs, n, "offs"))) return rc;
+    HIP_TRY(hipSetDevice(db->device));
+    // ---- sub-batches: cut at record boundaries, at most PIPE_RECORDS records / PIPE_BYTES bytes each
+    const int64_t PIPE_RECORDS = pipe_records(), PIPE_BYTES = (int64_t)96 << 20;
+    const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
+    if (!db->s_up) {
+        HIP_TRY(hipStreamCreateWithFlags(&db->s_up, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&db->s_run, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&db->s_down, hipStreamNonBlocking));
+        for (auto &sl : db->slot)
+            for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    }
+    for (auto &sl : db->slot) sl.used = false;
+    auto fin = [&](int code) {   // on any exit nothing of this call may still be in flight
+        (void)hipStreamSynchronize(db->s_up);
+        (void)hipStreamSynchronize(db->s_run);
+        (void)hipStreamSynchronize(db->s_down);
+        return code;
+    };
+#define PIPE_TRY(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess)                                                                            \
+            return fin(fail(e_ == hipErrorOutOfMemory ? STAG_E_NOMEM : STAG_E_HIP, "%s: %s (%s:%d)", #expr, \
+                            hipGetErrorString(e_), __FILE__, __LINE__));                                \
+    } while (0)
+    int64_t b0 = 0, j = 0;
+    while (b0 < n) {
+        int64_t b1 = std::min(n, b0 + PIPE_RECORDS);
+        if (offs[b1] - offs[b0] > PIPE_BYTES) {   // long records: fewer of them (at least one)
+            b1 = std::upper_bound(offs + b0 + 1, offs + b1 + 1, offs[b0] + PIPE_BYTES) - offs - 1;
+            b1 = std::max(b1, b0 + 1);
+        }
+        const int64_t m = b1 - b0;
+        stag_db::Slot &sl = db->slot[j & 1];
+        // the slot's previous sub-batch has left the device before its buffers are overwritten
+        if (sl.used) PIPE_TRY(hipEventSynchronize(sl.down));
+        // text: the 16-byte aligned stretch of the host text that holds records b0 .. b1 - 1 lands at the start of
+        // the slot's buffer; the kernels get a base pointer shifted by that stretch's offset, so the record
+        // offsets need no rebasing
+        const int64_t a0 = offs[b0] & ~(int64_t)15, a1 = offs[b1];
+        const int64_t span = (a1 - a0 + 15) / 16 * 16;
+        if ((rc = sl.text.reserve(span + 16)) || (rc = sl.offs.reserve(m + 1)) || (rc = sl.path_node.reserve(m * D)) ||
+            (rc = sl.path_prob.reserve(m * D)) || (rc = sl.path_len.reserve(m)) || (rc = sl.lead.reserve(m)) ||
+            (rc = sl.level_prob.reserve(m * K)) || (rc = sl.selected.reserve(m)) || (rc = sl.n_aligned.reserve(m)) ||
+            (rc = sl.status.reserve(m)) || (rc = sl.n_char.reserve(m)) || (bits_out && (rc = sl.bits.reserve((size_t)m * db->W))) ||
+            (rc = stag_db_reserve(db, m, span)))
+            return fin(rc);
+        PIPE_TRY(hipMemcpyAsync(sl.text.p, text + a0, a1 - a0, hipMemcpyHostToDevice, db->s_up));
+        PIPE_TRY(hipMemcpyAsync(sl.offs.p, offs + b0, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, db->s_up));
+        PIPE_TRY(hipEventRecord(sl.up, db->s_up));
+        // kernels: one compute stream, one workspace (the handle's); results into the slot's own buffers
+        PIPE_TRY(hipStreamWaitEvent(db->s_run, sl.up, 0));
+        Work wk = work_of(db);
+        if (bits_out) wk.bits = sl.bits.p;      // rows the caller wants leave through the slot, not the shared workspace
+        wk.enc_n_char = sl.n_char.p;
+        Out o;
+        o.path_node = sl.path_node.p; o.path_prob = sl.path_prob.p; o.path_len = sl.path_len.p; o.lead = sl.lead.p;
+        o.level_prob = sl.level_prob.p; o.selected = sl.selected.p; o.n_aligned = sl.n_aligned.p; o.status = sl.status.p;
+        const char *vbase = (const char *)sl.text.p - a0;      // record i of the sub-batch = vbase[offs[b0 + i] ..)
+        if ((rc = encode_dev(db, db->L, vbase, a0 + span, sl.offs.p, m, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
+                             wk.enc_status, wk.win, db->s_run)) ||
+            (rc = walk_dev(db, wk, wk.bits, m, wk.enc_status, o, false, db->s_run)))
+            return fin(rc);
+        PIPE_TRY(hipEventRecord(sl.done, db->s_run));
+        // results: straight into the caller's arrays at the sub-batch's position
+        PIPE_TRY(hipStreamWaitEvent(db->s_down, sl.done, 0));
+        auto down = [&](void *host, const void *dev, size_t bytes_per_seq) -> hipError_t {
+            if (!host) return hipSuccess;
+            return hipMemcpyAsync((char *)host + (size_t)b0 * bytes_per_seq, dev, (size_t)m * bytes_per_seq,
+                                  hipMemcpyDeviceToHost, db->s_down);
+        };
+        PIPE_TRY(down(out->path_node, sl.path_node.p, D * 4));
+        PIPE_TRY(down(out->path_prob, sl.path_prob.p, D * 8));
+        PIPE_TRY(down(out->path_len, sl.path_len.p, 4));
+        PIPE_TRY(down(out->n_lead_single, sl.lead.p, 4));
+        PIPE_TRY(down(out->level_prob, sl.level_prob.p, (size_t)db->n_keys * 8));
+        PIPE_TRY(down(out->selected, sl.selected.p, 4));
+        PIPE_TRY(down(out->n_aligned, sl.n_aligned.p, 4));
+        PIPE_TRY(down(out->status, sl.status.p, 4));
+        PIPE_TRY(down(bits_out, sl.bits.p, (size_t)db->W * 4));
+        PIPE_TRY(down(n_char_out, sl.n_char.p, 4));
+        PIPE_TRY(hipEventRecord(sl.down, db->s_down));
+        sl.used = true;
+        b0 = b1;
+        ++j;
+    }
+#undef PIPE_TRY
+    hipError_t e = hipStreamSynchronize(db->s_down);
+    if (e != hipSuccess) return fin(fail(STAG_E_HIP, "device to host copy failed: %s", hipGetErrorString(e)));
+    return fin(STAG_OK);
 }
 
 int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len, const uint32_t *const *rows,
@@ -815,10 +933,9 @@ int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *pr
         return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
     HIP_TRY(hipSetDevice(db->device));
-    const int64_t pb = prot_offs[n], gb = gene_offs[n];
-    if (prot_offs[0] < 0 || pb < prot_offs[0] || gene_offs[0] < 0 || gb < gene_offs[0])
-        return fail(STAG_E_INVALID, "offs must be non-decreasing");
     int rc;
+    if ((rc = check_offsets(prot_offs, n, "prot_offs")) || (rc = check_offsets(gene_offs, n, "gene_offs"))) return rc;
+    const int64_t pb = prot_offs[n], gb = gene_offs[n];
     if ((rc = db->text.reserve(pb + 16)) || (rc = db->offs.reserve(n + 1)) || (rc = db->gene_text.reserve(gb + 16)) ||
         (rc = db->gene_offs.reserve(n + 1)))
         return rc;
@@ -858,6 +975,18 @@ int stag_backtranslate(const char *prot, int64_t prot_len, const char *gene, int
     }
     *out_len = o;
     return STAG_OK;
+}
+
+void *stag_host_alloc(int64_t bytes) {
+    void *p = nullptr;
+    if (bytes < 0) { fail(STAG_E_INVALID, "negative size"); return nullptr; }
+    const hipError_t e = hipHostMalloc(&p, (size_t)std::max<int64_t>(bytes, 1), hipHostMallocDefault);
+    if (e != hipSuccess) { fail(STAG_E_NOMEM, "hipHostMalloc(%lld): %s", (long long)bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+
+void stag_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int stag_profile_enable(stag_db_t *db, int32_t on) {

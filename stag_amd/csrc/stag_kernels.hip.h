@@ -211,7 +211,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     // (all ones except in a record's first and last vector)
     auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (rel < len && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
+        if (rel < len && p >= 0 && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         const int lo_cut = min(16, max(0, -rel));
         const int hi_cut = min(16, max(0, len - rel));

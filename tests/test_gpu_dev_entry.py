@@ -241,3 +241,56 @@ def test_two_handles_on_two_streams_are_independent():
         finally:
             for st in streams:
                 H.hipStreamDestroy(st)
+
+
+def test_host_pipeline_sub_batches_pinned_and_pageable(monkeypatch):
+    """stag_classify_a2m is a pipeline over sub-batches (text up / kernels / results down on three streams).
+    Forced to 97-record sub-batches it must give what one sub-batch gives, bit for bit, with pageable and with
+    page-locked (stag_host_alloc) buffers, with and without the packed rows coming back; and a malformed
+    offsets array is refused before anything is copied."""
+    rng = np.random.default_rng(8)
+    ncol = 210
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[4], [1, 2, 5], [0, 2, 3], [2]], 0.07)
+    strings = amplicon_strings(rng, ncol, 3001)
+    text, offs = tables.pack_text(strings)
+    n = len(strings)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        monkeypatch.setenv("STAG_PIPE_RECORDS", "1000000")
+        ref = db.classify_a2m_text(text, offs, min_perc_state=15.0, want_bits=True)
+        assert len(set(ref.status.tolist())) >= 3
+        monkeypatch.setenv("STAG_PIPE_RECORDS", "97")
+        for want_bits in (True, False):
+            got = db.classify_a2m_text(text, offs, min_perc_state=15.0, want_bits=want_bits)
+            for f in FIELDS + ("n_char",) + (("bits",) if want_bits else ()):
+                assert np.array_equal(getattr(got, f), getattr(ref, f)), f
+        # page-locked buffers for everything the call touches
+        D, K, W = db.max_depth, db.n_keys, db.words_per_row
+        p_text, p_offs = _lib.PinnedArray(len(text), np.uint8), _lib.PinnedArray(n + 1, np.int64)
+        p_text.a[:] = text
+        p_offs.a[:] = offs
+        shapes = {"path_node": ((n, D), np.int32), "path_prob": ((n, D), np.float64), "path_len": (n, np.int32),
+                  "n_lead_single": (n, np.int32), "level_prob": ((n, K), np.float64), "selected": (n, np.int32),
+                  "n_aligned": (n, np.int32), "status": (n, np.int32)}
+        pinned = {f: _lib.PinnedArray(*sd) for f, sd in shapes.items()}
+        p_bits, p_char = _lib.PinnedArray((n, W), np.uint32), _lib.PinnedArray(n, np.int32)
+        res = _lib.Results()
+        for f in shapes:
+            setattr(res, f, _lib.ptr(pinned[f].a))
+        for _ in range(2):
+            for arr in list(pinned.values()) + [p_bits, p_char]:
+                arr.a[...] = 0
+            _lib.check(_lib.lib().stag_classify_a2m(db.handle, _lib.ptr(p_text.a), _lib.ptr(p_offs.a), n, 15.0,
+                                                    ctypes.byref(res), _lib.ptr(p_bits.a), _lib.ptr(p_char.a)))
+            for f in shapes:
+                assert np.array_equal(pinned[f].a, getattr(ref, f).reshape(pinned[f].a.shape)), f
+            assert np.array_equal(p_bits.a, ref.bits) and np.array_equal(p_char.a, ref.n_char)
+        # offsets that step backwards in the middle (they would send the kernel outside the text)
+        bad = offs.copy()
+        bad[1500] = bad[1499] - 5
+        st = ref.as_struct()
+        rc = _lib.lib().stag_classify_a2m(db.handle, _lib.ptr(text), _lib.ptr(bad), n, 0.0, ctypes.byref(st), None, None)
+        assert rc == -1 and b"non-decreasing" in _lib.lib().stag_last_error()
+        bad = offs.copy()
+        bad[0] = -16
+        assert _lib.lib().stag_classify_a2m(db.handle, _lib.ptr(text), _lib.ptr(bad), n, 0.0, ctypes.byref(st), None, None) == -1

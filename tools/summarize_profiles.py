@@ -14,7 +14,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r1"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+sys.path.insert(0, ROOT)
+from stag_amd._lib import kernel_source_sha1  # noqa: E402
 
 
 def short(name):
@@ -51,6 +53,7 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over 
                "step). Counter values are KiB as rocprofv3 reports them (x1024 -> bytes); FETCH_SIZE is doubled "
                "for gfx950 as MI355X_MICROARCH.md (HBM section) prescribes, which over-counts kernels whose "
                "reads are narrow. hbm_bytes_per_launch = (2*FETCH + WRITE) / dispatches.",
+       "kernel_source_sha1": kernel_source_sha1(),   # bench.py reports traffic only for a build from these sources
        "kernels": {}}
 for k in fetch:
     if not k.startswith("k_"):
