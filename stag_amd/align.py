@@ -122,7 +122,7 @@ def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
     size = size or BATCH_RECORDS
     align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
     if not protein_file:
-        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size):
+        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size, pinned=True):
             yield ids, text, offs, None
         _finish_aligner(align_proc, parse_proc)
         return

@@ -78,14 +78,45 @@ def _fill(stream, buf, have):
     return have, False
 
 
-def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False):
+class _TextRing:
+    """Two page-locked text buffers (stag_host_alloc) used in turn: the batch handed to the caller sits in one
+    while the next is assembled in the other, so the GPU's copy engine reads batches by DMA (the pipeline of
+    stag_classify_a2m overlaps its copies only from such memory).  Without a usable GPU library the buffers
+    are ordinary arrays."""
+
+    def __init__(self):
+        self.bufs, self.turn, self.ok = [None, None], 0, True
+
+    def take(self, nbytes):
+        self.turn ^= 1
+        cur = self.bufs[self.turn]
+        if cur is not None and len(cur[1]) >= nbytes:
+            return cur[1][:nbytes]
+        arr = None
+        if self.ok:
+            try:
+                from . import _lib
+                keep = _lib.PinnedArray(max(nbytes + (nbytes >> 2), 1 << 20), np.uint8)
+                arr = (keep, keep.a)
+            except Exception:
+                self.ok = False
+        if arr is None:
+            arr = (None, np.empty(nbytes, dtype=np.uint8))
+        self.bufs[self.turn] = arr
+        return arr[1][:nbytes]
+
+
+def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False, pinned=False):
     """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
     (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1); with
     text_mode, as read_fasta(open(path), is_binary=False): universal newlines, so a lone '\r' also
     ends a line (the gene file of align.py:150).  batch_records is a target, not a bound: records
-    that had to be re-parsed the slow way are all added to the batch that was being filled."""
+    that had to be re-parsed the slow way are all added to the batch that was being filled.
+    pinned: the text arrays are views of two page-locked buffers used in turn (a batch stays valid until the
+    batch after the next one is produced)."""
     L = lib()
+    ring = _TextRing() if pinned else None
     buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
     scratch = np.empty(len(buf), dtype=np.uint8)
     have, at_start, ended = 0, True, False
@@ -93,7 +124,11 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
 
     def flush():
         nonlocal ids, texts, offs_parts, total
-        text = np.zeros(total + (-total % 16), dtype=np.uint8)
+        if ring is None:
+            text = np.zeros(total + (-total % 16), dtype=np.uint8)
+        else:
+            text = ring.take(total + (-total % 16))
+            text[total:] = 0
         at = 0
         for t in texts:
             text[at:at + len(t)] = t

@@ -211,3 +211,27 @@ def test_onehot_parse_random_files_equal_the_per_line_parser(tmp_path):
             assert [g[0] for g in got] == [w[0] for w in want], (case, L, chunk, rows, data)
             for g, w in zip(got, want):
                 assert g[1] == len(w[1]) and (g[2] is None or g[2] == [int(v) for v in w[1]]), (case, L, chunk, rows, data)
+
+
+def test_fasta_batches_in_the_two_buffer_ring_equal_plain_batches():
+    """pinned=True hands out views of two buffers used in turn (page-locked when a GPU library is usable, plain
+    arrays here): same batches as without, and a batch is still intact after the next one has been produced."""
+    import io
+    from stag_amd import ingest
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(700):
+        seq = "".join(rng.choice(list("ACGT-acgt."), size=int(rng.integers(0, 300))))
+        recs.append(">r%d x\n%s\n" % (i, "\n".join(seq[j:j + 50] for j in range(0, len(seq), 50))))
+    data = "".join(recs).encode()
+    plain = list(ingest.fasta_batches(io.BytesIO(data), batch_records=64, chunk_bytes=4096))
+    prev = None
+    count = 0
+    for k, (ids, text, offs) in enumerate(ingest.fasta_batches(io.BytesIO(data), batch_records=64, chunk_bytes=4096, pinned=True)):
+        assert ids == plain[k][0] and np.array_equal(offs, plain[k][2]) and np.array_equal(text, plain[k][1])
+        assert len(text) % 16 == 0
+        if prev is not None:
+            assert np.array_equal(prev[0], plain[k - 1][1])      # the batch before is still what it was
+        prev = (text, k)
+        count += 1
+    assert count == len(plain) and count > 5
