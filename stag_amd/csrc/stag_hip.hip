@@ -213,7 +213,8 @@ int launch_check(const char *what) {
 
 int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
                double min_perc, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned, int32_t *d_status,
-               uint32_t *d_win, hipStream_t st, const int64_t *d_ends = nullptr, const int32_t *d_pre_status = nullptr) {
+               uint32_t *d_win, hipStream_t st, const int64_t *d_ends = nullptr, const int32_t *d_pre_status = nullptr,
+               bool full_rows = true) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
@@ -244,7 +245,13 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
                            d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win, d_ends, d_pre_status);
         return STAG_OK;
     };
-    int rc = G == 64 ? launch(k_encode_a2m<64>) : G == 32 ? launch(k_encode_a2m<32>) : launch(k_encode_a2m<16>);
+    // full_rows: the caller reads the rows (stag_encode_a2m*, bits_out); otherwise only the walk does, and it
+    // needs no more than each row's window chunks
+    int rc;
+    if (full_rows || !d_win)
+        rc = G == 64 ? launch(k_encode_a2m<64, true>) : G == 32 ? launch(k_encode_a2m<32, true>) : launch(k_encode_a2m<16, true>);
+    else
+        rc = G == 64 ? launch(k_encode_a2m<64, false>) : G == 32 ? launch(k_encode_a2m<32, false>) : launch(k_encode_a2m<16, false>);
     if (rc) return rc;
     return launch_check("k_encode_a2m");
 }
@@ -672,7 +679,7 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
     const Out o = resolve(db, d_out);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = encode_dev(db, db->L, d_text, text_bytes, d_offs, n, min_perc_state, db->bits.p, db->enc_n_char.p,
-                         o.n_aligned, db->enc_status.p, db->win.p, st)))
+                         o.n_aligned, db->enc_status.p, db->win.p, st, nullptr, nullptr, /*full_rows=*/false)))
         return rc;
     return walk_dev(db, work_of(db), db->bits.p, n, db->enc_status.p, o, false, st);
 }
@@ -731,7 +738,7 @@ int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t tex
     hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = encode_dev(nullptr, db->L, d_text, text_bytes, d_offs, n, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
-                         wk.enc_status, wk.win, st)))
+                         wk.enc_status, wk.win, st, nullptr, nullptr, /*full_rows=*/false)))
         return rc;
     return walk_dev(db, wk, wk.bits, n, wk.enc_status, o, false, st);
 }
@@ -802,7 +809,7 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         o.level_prob = sl.level_prob.p; o.selected = sl.selected.p; o.n_aligned = sl.n_aligned.p; o.status = sl.status.p;
         const char *vbase = (const char *)sl.text.p - a0;      // record i of the sub-batch = vbase[offs[b0 + i] ..)
         if ((rc = encode_dev(db, db->L, vbase, a0 + span, sl.offs.p, m, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
-                             wk.enc_status, wk.win, db->s_run)) ||
+                             wk.enc_status, wk.win, db->s_run, nullptr, nullptr, /*full_rows=*/bits_out != nullptr)) ||
             (rc = walk_dev(db, wk, wk.bits, m, wk.enc_status, o, false, db->s_run)))
             return fin(rc);
         PIPE_TRY(hipEventRecord(sl.done, db->s_run));
@@ -900,9 +907,20 @@ int stag_backtranslate_dev(const char *d_prot, int64_t prot_bytes, const int64_t
     return launch_check("k_backtranslate");
 }
 
+static int classify_protein_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
+                                const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
+                                const stag_results_t *d_out, void *stream, bool full_rows);
+
 int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
                                   const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
                                   const stag_results_t *d_out, void *stream) {
+    return classify_protein_dev(db, d_prot, prot_bytes, d_prot_offs, d_gene, d_gene_offs, n, min_perc_state, d_out, stream,
+                                /*full_rows=*/false);
+}
+
+static int classify_protein_dev(stag_db_t *db, const char *d_prot, int64_t prot_bytes, const int64_t *d_prot_offs,
+                                const char *d_gene, const int64_t *d_gene_offs, int64_t n, double min_perc_state,
+                                const stag_results_t *d_out, void *stream, bool full_rows) {
     if (!db || n < 0 || prot_bytes < 0 || (n > 0 && (!d_prot || !d_prot_offs || !d_gene || !d_gene_offs)))
         return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
@@ -921,7 +939,8 @@ int stag_classify_protein_a2m_dev(stag_db_t *db, const char *d_prot, int64_t pro
     }
     const Out o = resolve(db, d_out);
     if ((rc = encode_dev(db, db->L, (const char *)db->bt_text.p, bt_bytes, db->bt_begin.p, n, min_perc_state, db->bits.p,
-                         db->enc_n_char.p, o.n_aligned, db->enc_status.p, db->win.p, st, db->bt_end.p, db->bt_status.p)))
+                         db->enc_n_char.p, o.n_aligned, db->enc_status.p, db->win.p, st, db->bt_end.p, db->bt_status.p,
+                         full_rows)))
         return rc;
     return walk_dev(db, work_of(db), db->bits.p, n, db->enc_status.p, o, false, st);
 }
@@ -943,8 +962,8 @@ int stag_classify_protein_a2m(stag_db_t *db, const char *prot, const int64_t *pr
     HIP_TRY(hipMemcpy(db->offs.p, prot_offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db->gene_text.p, gene, gb, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(db->gene_offs.p, gene_offs, (n + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    if ((rc = stag_classify_protein_a2m_dev(db, (const char *)db->text.p, pb, db->offs.p, (const char *)db->gene_text.p,
-                                            db->gene_offs.p, n, min_perc_state, nullptr, nullptr)))
+    if ((rc = classify_protein_dev(db, (const char *)db->text.p, pb, db->offs.p, (const char *)db->gene_text.p,
+                                   db->gene_offs.p, n, min_perc_state, nullptr, nullptr, /*full_rows=*/bits_out != nullptr)))
         return rc;
     if ((rc = copy_results_to_host(db, out, n, nullptr))) return rc;
     if (bits_out) HIP_TRY(hipMemcpy(bits_out, db->bits.p, (size_t)n * db->W * 4, hipMemcpyDeviceToHost));

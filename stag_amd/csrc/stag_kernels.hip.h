@@ -137,8 +137,8 @@ __device__ __forceinline__ int group_reduce_last(int v, const int identity, F f)
     return v;
 }
 
-// The record's LDS row starts as R0 (every column a gap).  A lane XORs in, for each of its k
-// columns, (one-hot group ^ gap group) at column running + before: zero for a gap, so lanes and
+// The record's LDS row holds the record's difference from R0 (every column a gap).  A lane XORs in, for each
+// of its k columns, (one-hot group ^ gap group) at column running + before: zero for a gap, so lanes and
 // steps that only see gaps touch nothing.  lo: bits 0..63, hi: bits 64..79 of the k groups.
 // w_lo / w_hi track the words this lane changed (the row's window comes from them).
 __device__ __forceinline__ void emit_groups(uint32_t *row, int W, int col, uint64_t lo, uint32_t hi, int &w_lo, int &w_hi) {
@@ -162,7 +162,12 @@ __device__ __forceinline__ void emit_groups(uint32_t *row, int W, int col, uint6
 // G = lanes per record (16, 32 or 64): a wave encodes 64/G records side by side, each lane
 // taking 16 bytes of its record per step.  The host picks G so that a record's length wastes few
 // lane slots (a 1,501-byte record is 2 steps of 64 lanes = 2,048 slots, or 3 steps of 32 = 1,536).
-template <int G>
+// FULL: every word of the row is stored (stag_encode_a2m*, -S).  !FULL (the classify paths): only the 16-word
+// chunks that hold the row's window are stored -- everything else equals R0, which the walk never reads from
+// memory (k_walk_level scores a row outside its own window from the gap chains) -- so an amplicon read costs
+// 192 B of row traffic instead of 944.  The words of such a row outside its window chunks keep whatever the
+// buffer held before.
+template <int G, bool FULL>
 __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ text, int64_t text_bytes,
                                                     const int64_t *__restrict__ offs, int64_t n, int L, int W,
                                                     double min_perc, uint32_t *__restrict__ rows,
@@ -183,19 +188,9 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t seq = ((int64_t)blockIdx.x * 4 + wave) * RPW + grp;
     const bool live = seq < n;
     uint32_t *row = s_enc + (size_t)(wave * RPW + grp) * W;
-    for (int w = gl * 4; w < W; w += 4 * G) {   // the row starts as R0: all gaps (W is a multiple of 4)
-        uint32_t r[4];
-        if ((int64_t)(w + 4) * 32 <= L) {
-            const int s5 = (5 - (2 * w) % 5) % 5;
-            const uint64_t r01 = 0x1084210842108421ull << s5, r23 = 0x1084210842108421ull << (s5 == 4 ? 0 : s5 + 1);
-            r[0] = (uint32_t)r01; r[1] = (uint32_t)(r01 >> 32); r[2] = (uint32_t)r23; r[3] = (uint32_t)(r23 >> 32);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = r0_word(w + j, L);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) row[w + j] = r[j];
-    }
+    // the LDS row collects what the record CHANGES relative to R0 (all gaps): it starts as zeros and is XOR-ed
+    // with R0 on its way out (W is a multiple of 4)
+    for (int w = gl * 4; w < W; w += 4 * G) *reinterpret_cast<uint4 *>(row + w) = make_uint4(0u, 0u, 0u, 0u);
     int w_lo = 0x7fffffff, w_hi = 0;     // words this lane changes
 
     const int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
@@ -317,10 +312,28 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const int64_t valid_bits = 5ll * running;
     const bool short_row = valid_bits < (int64_t)L;
     if (short_row) { lo4 = 0; hi4 = W >> 2; }
-    for (int w = gl * 4; w < W; w += 4 * G) {
+    // words to store: all of them, or the 16-word chunks around the window (what the walk stages)
+    int st_lo = 0, st_hi = W;
+    if (!FULL) {
+        const int last = (lane & ~(G - 1)) + G - 1;      // the group's last lane holds the reduced window
+        const int l4 = __shfl(lo4, last), h4 = __shfl(hi4, last);
+        const bool sr = __shfl((int)short_row, last) != 0;
+        st_lo = (l4 * 4) & ~(CHUNK_WORDS - 1);
+        st_hi = min(W, (h4 * 4 + CHUNK_WORDS - 1) & ~(CHUNK_WORDS - 1));
+        if (h4 <= l4 || sr) st_hi = st_lo = 0;           // equals R0 everywhere / never classified: nothing to store
+    }
+    for (int w = st_lo + gl * 4; w < st_hi; w += 4 * G) {
         if (!live) break;
         uint32_t v[4] = {row[w], row[w + 1], row[w + 2], row[w + 3]};
-        if (short_row) {
+        if ((int64_t)(w + 4) * 32 <= L) {
+            const int s5 = (5 - (2 * w) % 5) % 5;
+            const uint64_t r01 = 0x1084210842108421ull << s5, r23 = 0x1084210842108421ull << (s5 == 4 ? 0 : s5 + 1);
+            v[0] ^= (uint32_t)r01; v[1] ^= (uint32_t)(r01 >> 32); v[2] ^= (uint32_t)r23; v[3] ^= (uint32_t)(r23 >> 32);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] ^= r0_word(w + j, L);
+        }
+        if (FULL && short_row) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int64_t nb = valid_bits - 32ll * (w + j);
