@@ -5,6 +5,7 @@
 #include "stag_kernels.hip.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -126,6 +127,16 @@ struct stag_db {
     DevBuf<Task> tasks;
     DevBuf<uint32_t> bits, win;
     DevBuf<double> gappre, gapsuf;
+    // tables of the matrix-core walk (k_walk_mfma): per parent node the union of its children's features per
+    // chunk and the children's coefficients as signed base-256 digits of a fixed-point number
+    DevBuf<uint32_t> pf_off, pfeat;
+    DevBuf<int8_t> dig;
+    DevBuf<uint64_t> dig_base;
+    DevBuf<uint32_t> dig_ld;
+    DevBuf<double> qscale;
+    DevBuf<uint8_t> mfma_ok;
+    std::vector<uint8_t> level_has_mfma, level_has_gather;   // per level: are there tasks for either kernel?
+    int walk_mode = 0;                                         // 0 auto, 1 gather only (STAG_WALK=gather)
     DevBuf<uint8_t> text, gene_text, bt_text;
     DevBuf<int64_t> offs, gene_offs, bt_begin, bt_end;
     DevBuf<int32_t> bt_status;
@@ -153,6 +164,7 @@ struct stag_db {
     void free_all() {
         child_first.release(); node_err.release(); intercept.release(); blk_off.release();
         blocks.release(); tf.release(); node.release(); pos.release(); order.release();
+        pf_off.release(); pfeat.release(); dig.release(); dig_base.release(); dig_ld.release(); qscale.release(); mfma_ok.release();
         count.release(); lvl.release(); task_off.release(); n_tasks.release(); tasks.release();
         bits.release(); win.release(); gappre.release(); gapsuf.release(); text.release(); offs.release();
         gene_text.release(); bt_text.release(); gene_offs.release(); bt_begin.release(); bt_end.release(); bt_status.release(); enc_n_char.release(); enc_status.release();
@@ -343,7 +355,7 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         if (d == 0) {
             Prof p(db, st, 2, wk.prof);
             hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, wk.win, cur,
-                               db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks);
+                               db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks, db->blk_off.p, db->nchunks);
         } else {
             Prof p(db, st, 2, wk.prof);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
@@ -352,7 +364,8 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
             hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, wk.count, db->child_first.p,
                                db->node_err.p, wk.task_off, wk.n_tasks + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, wk.node, wk.pos, wk.count,
-                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks, cur, o.status);
+                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks, cur, o.status,
+                               db->blk_off.p, db->nchunks);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
@@ -363,7 +376,18 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         a.lvl = cur; a.status = o.status;
         a.gappre = db->gappre.p; a.gapsuf = db->gapsuf.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
-        {
+        // nodes with matrix-core tables are walked by k_walk_mfma, the others (children beyond its column blocks,
+        // coefficients that are not finite, STAG_WALK=gather) by k_walk_level; a level launches what it has
+        const bool has_mfma = db->level_has_mfma[d], has_gather = db->level_has_gather[d];
+        a.mfma_ok = has_mfma ? db->mfma_ok.p : nullptr;
+        if (has_mfma) {
+            MfmaArgs m;
+            m.pf_off = db->pf_off.p; m.pfeat = db->pfeat.p; m.dig = db->dig.p; m.dig_base = db->dig_base.p;
+            m.dig_ld = db->dig_ld.p; m.qscale = db->qscale.p; m.mfma_ok = db->mfma_ok.p;
+            Prof p(db, st, 1, wk.prof);
+            hipLaunchKernelGGL(k_walk_mfma, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a, m);
+        }
+        if (has_gather) {
             Prof p(db, st, 1, wk.prof);
             hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
         }
@@ -547,6 +571,112 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     }
     blk_off[(size_t)n * nch] = (uint32_t)(entries.size() / BLOCK_ENTRIES);
 
+    // ---- matrix-core tables.  For a parent p whose k children are all scored (2 <= k <= MFMA_MAX_K), chunk by
+    // chunk: U = the sorted union of the children's features in the chunk, padded to a multiple of 16 (a padding
+    // feature reads the chunk's first word and has all-zero digits); every coefficient w becomes the integer
+    // v = round(w * 2^q) (q per parent: the largest with max |v| < 2^46) written as 6 signed base-256 digits.
+    // dig holds, per parent, a matrix [columns][features of the parent]: column 16 (j / 2) + 8 (j % 2) + s = digit s
+    // of child j (two children per block of 16 columns, columns 6 and 7 of each half are zero).  The kernel multiplies the 0/1 feature bytes of 64 rows with it on
+    // the matrix cores (v_mfma_i32_16x16x64_i8): integer arithmetic, exact and order-independent.
+    std::vector<uint32_t> pf_off((size_t)n * nch + 1, 0), pfeat, dig_ld(n, 0);
+    std::vector<uint64_t> dig_base(n, 0);
+    std::vector<double> qscale(n, 0.0);
+    std::vector<uint8_t> mfma_ok(n, 0);
+    std::vector<int8_t> dig;
+    const char *walk_env = getenv("STAG_WALK");
+    db->walk_mode = walk_env && !strcmp(walk_env, "gather") ? 1 : 0;
+    {
+        std::vector<int32_t> ufeat;                    // union features of one chunk
+        std::vector<size_t> at;                        // per child: next coefficient
+        for (int p = 0; p < n; ++p) {
+            const int c0 = t->child_first[p], k = t->child_first[p + 1] - c0;
+            bool ok = db->walk_mode == 0 && k >= 2 && k <= MFMA_MAX_K && !node_err[p];
+            double wmax = 0.0;
+            if (ok)
+                for (int c = c0; c < c0 + k && ok; ++c) {
+                    if (!(std::fabs(t->intercept[c]) < 1e300)) { ok = false; break; }
+                    for (int64_t e = t->row_off[c]; e < t->row_off[c + 1]; ++e) {
+                        const double w = t->row_w[e];
+                        if (!(std::fabs(w) < 1e30)) { ok = false; break; }     // inf / NaN: the gather walk keeps their semantics
+                        wmax = std::max(wmax, std::fabs(w));
+                    }
+                }
+            const size_t first_feat = pfeat.size();
+            if (ok) {
+                int q = 80;
+                if (wmax > 0.0) { int ex; std::frexp(wmax, &ex); q = std::min(80, 46 - ex); }   // wmax < 2^ex
+                const double scale = std::ldexp(1.0, q);
+                at.assign(k, 0);
+                for (int j = 0; j < k; ++j) at[j] = (size_t)t->row_off[c0 + j];
+                // pass 1: the union per chunk -> descriptors; remember each chunk's range
+                std::vector<std::pair<size_t, size_t>> chunk_range(nch);
+                for (int ch = 0; ch < nch; ++ch) {
+                    pf_off[(size_t)p * nch + ch] = (uint32_t)pfeat.size();
+                    const int64_t f_end = (int64_t)(ch + 1) * CHUNK_WORDS * 32;
+                    ufeat.clear();
+                    for (int j = 0; j < k; ++j) {
+                        size_t e = at[j];
+                        const size_t e1 = (size_t)t->row_off[c0 + j + 1];
+                        while (e < e1 && t->row_feat[e] < f_end) ufeat.push_back(t->row_feat[e++]);
+                        at[j] = e;
+                    }
+                    std::sort(ufeat.begin(), ufeat.end());
+                    ufeat.erase(std::unique(ufeat.begin(), ufeat.end()), ufeat.end());
+                    const size_t b = pfeat.size();
+                    for (int32_t f : ufeat) pfeat.push_back(4u * (uint32_t)(f >> 5) | ((uint32_t)(f & 31) << 16));
+                    while ((pfeat.size() - first_feat) % 16) pfeat.push_back(4u * (uint32_t)(ch * CHUNK_WORDS));
+                    chunk_range[ch] = {b, pfeat.size()};
+                }
+                const size_t U = pfeat.size() - first_feat;
+                const size_t ncolp = (size_t)((k + 1) / 2) * 16;      // two children per block of 16 columns
+                if (U > 0xffffff0u || pfeat.size() > 0xfffffff0u) { delete db; return fail(STAG_E_INVALID, "feature table too large"); }
+                dig_base[p] = dig.size();
+                dig_ld[p] = (uint32_t)U;
+                qscale[p] = std::ldexp(1.0, -q);
+                dig.resize(dig.size() + ncolp * U, 0);
+                int8_t *M = dig.data() + dig_base[p];
+                // pass 2: digits.  Features of a chunk are sorted, so a child's coefficient is found by merging.
+                for (int j = 0; j < k; ++j) {
+                    size_t e = (size_t)t->row_off[c0 + j];
+                    const size_t e1 = (size_t)t->row_off[c0 + j + 1];
+                    for (int ch = 0; ch < nch && e < e1; ++ch) {
+                        size_t u = chunk_range[ch].first;
+                        const int64_t f_end = (int64_t)(ch + 1) * CHUNK_WORDS * 32;
+                        while (e < e1 && t->row_feat[e] < f_end) {
+                            const uint32_t want = 4u * (uint32_t)(t->row_feat[e] >> 5) | ((uint32_t)(t->row_feat[e] & 31) << 16);
+                            while (pfeat[u] != want) ++u;       // present by construction
+                            long long v = std::llround(t->row_w[e] * scale);
+                            for (int sl = 0; sl < MFMA_SLICES; ++sl) {
+                                const long long d = ((v + 128) & 255) - 128;
+                                M[((size_t)(j >> 1) * 16 + (size_t)(j & 1) * 8 + sl) * U + (u - first_feat)] = (int8_t)d;
+                                v = (v - d) >> 8;
+                            }
+                            if (v != 0) { ok = false; }          // cannot happen with |v| < 2^46
+                            ++e;
+                        }
+                    }
+                }
+            }
+            if (!ok) {      // no tables for this node: it is walked by the gather kernel
+                pfeat.resize(first_feat);
+                for (int ch = 0; ch < nch; ++ch) pf_off[(size_t)p * nch + ch] = (uint32_t)first_feat;
+                if (dig_ld[p]) { dig.resize(dig_base[p]); dig_ld[p] = 0; }
+            }
+            mfma_ok[p] = ok ? 1 : 0;
+        }
+        pf_off[(size_t)n * nch] = (uint32_t)pfeat.size();
+        for (int i = 0; i < 256; ++i) pfeat.push_back(0u);     // the kernel reads descriptors / digits a block at a time
+        dig.resize(dig.size() + 4096, 0);
+    }
+    db->level_has_mfma.assign(db->max_depth + 1, 0);
+    db->level_has_gather.assign(db->max_depth + 1, 0);
+    for (int d = 0; d < db->max_depth; ++d)
+        for (int p = db->level_start[d]; p < db->level_start[d + 1]; ++p) {
+            const int k = t->child_first[p + 1] - t->child_first[p];
+            if (k < 2 || node_err[p]) continue;
+            (mfma_ok[p] ? db->level_has_mfma : db->level_has_gather)[d] = 1;
+        }
+
 #define UP(buf, vec, T)                                                                              \
     do {                                                                                             \
         if ((rc = db->buf.reserve((vec).size()))) { db->free_all(); delete db; return rc; }          \
@@ -560,6 +690,13 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     std::vector<double> tfv(t->tf ? t->tf : nullptr, t->tf ? t->tf + (size_t)t->n_keys * (1 + t->n_tf) : nullptr);
     UP(gappre, gappre, double);
     UP(gapsuf, gapsuf, double);
+    UP(pf_off, pf_off, uint32_t);
+    UP(pfeat, pfeat, uint32_t);
+    UP(dig, dig, int8_t);
+    UP(dig_base, dig_base, uint64_t);
+    UP(dig_ld, dig_ld, uint32_t);
+    UP(qscale, qscale, double);
+    UP(mfma_ok, mfma_ok, uint8_t);
     UP(child_first, cf, int32_t);
     UP(node_err, node_err, uint8_t);
     UP(intercept, ic, double);

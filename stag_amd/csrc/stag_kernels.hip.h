@@ -32,6 +32,8 @@ constexpr int CHUNK_WORDS = 16;   // row words per coefficient chunk (= one 64-b
 constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80 words, 320 B per row)
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
 constexpr int BLOCK_ENTRIES = 4;  // coefficient lists are padded to 4 entries per (row, chunk)
+constexpr int MFMA_SLICES = 6;    // signed base-256 digits per coefficient in the matrix-core walk
+constexpr int MFMA_MAX_K = 16;    // children per node it handles: two per block of 16 columns, 8 blocks
 static_assert(WCAP_CHUNKS * CHUNK_WORDS == 64, "a staged slice is one dword per lane and row: all 64 lanes store into a row of ROW_STRIDE words");
 
 struct Entry {      // 16 bytes
@@ -48,10 +50,18 @@ __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
     return (const T STAG_CONST *)(uintptr_t)p;
 }
 
-struct Task {       // 32 bytes: one s_load_dwordx8 tells a workgroup everything about its task
-    int32_t node, pad2, count, err;    // err: status every sequence reaching this node gets (0 = fine)
-    int32_t c0, k, pad0, pad1;         // children of node: ids c0 .. c0+k-1 (k == 0: a leaf, the walk ends)
+struct Task {       // 64 bytes: one s_load_dwordx16 tells a workgroup everything about its task
+    int32_t node, count;
+    int32_t c0, k;                     // children of node: ids c0 .. c0+k-1, k >= 2 (other nodes get no task)
+    // HINT: where the coefficients of the first NW siblings (one per wave) sit for the window [hA, hB) (chunks) of
+    // the task's first sequence -- looked up by the grouping kernel, where a million threads hide the two
+    // dependent loads, instead of by every wave of the walk.  Tasks are mostly made of rows with the same
+    // window (amplicon reads); when the union of the task's windows differs, the walk looks them up itself.
+    int32_t hA, hB;
+    int32_t pad0, pad1;
+    uint32_t e_lo[4], e_hi[4];         // in entries
 };
+static_assert(sizeof(Task) == 64, "one s_load_dwordx16");
 // order[]: a sequence id and its R0 window, so the walk needs one load, not two.  Task t owns the
 // 64 slots order[64 t .. 64 t + 63] (the first `count` are filled): the walk can fetch its task
 // record and its sequences at the same time instead of one after the other.
@@ -68,6 +78,7 @@ struct __attribute__((aligned(16))) LevelRec {
 };
 // plain vector types: unlike HIP's uint4 class they can be loaded from the constant address space
 using i32x8 = __attribute__((ext_vector_type(8))) int32_t;
+using i32x16 = __attribute__((ext_vector_type(16))) int32_t;
 
 // ------------------------------------------------------------------------------------------
 // encode: stag/align.py:28-58 (+ the filter of :160).  One wave per aligned string.
@@ -674,13 +685,36 @@ __device__ __forceinline__ void settle_trivial(int c0, int k, int err, int64_t s
     cur[s] = r;
 }
 
+// The task record of <= 64 sequences of node nd, with the hint (see Task) taken from one of its sequences' window.
+__device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint32_t win, const uint32_t *__restrict__ blk_off,
+                                          int NC) {
+    Task tk;
+    tk.node = nd; tk.count = count; tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
+    const int l4 = (int)(win & 0xffffu), h4 = (int)(win >> 16);
+    int hA = 0, hB = 0;
+    if (h4 > l4) { hA = l4 >> 2; hB = min((h4 + 3) >> 2, NC); }
+    tk.hA = hA; tk.hB = hB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t e0 = 0, e1 = 0;
+        if (j < k && hB > hA) {
+            const uint32_t *bo = blk_off + (size_t)(c0 + j) * NC;
+            e0 = bo[hA] * BLOCK_ENTRIES;
+            e1 = bo[hB] * BLOCK_ENTRIES;
+        }
+        tk.e_lo[j] = e0; tk.e_hi[j] = e1;
+    }
+    return tk;
+}
+
 __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, const int32_t *__restrict__ node,
                                                  const int32_t *__restrict__ pos, const int32_t *__restrict__ count,
                                                  const int32_t *__restrict__ task_off,
                                                  const int32_t *__restrict__ child_first,
                                                  const uint8_t *__restrict__ node_err, const uint32_t *__restrict__ win,
                                                  SeqRef *__restrict__ order, Task *__restrict__ tasks,
-                                                 LevelRec *__restrict__ cur, int32_t *__restrict__ status) {
+                                                 LevelRec *__restrict__ cur, int32_t *__restrict__ status,
+                                                 const uint32_t *__restrict__ blk_off, int NC) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int nd = node[s];
@@ -696,12 +730,7 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
     ref.seq = (int32_t)s;
     ref.win = win[s];
     order[(size_t)task * TILE + (p & (TILE - 1))] = ref;
-    if ((p & (TILE - 1)) == 0) {
-        Task tk;
-        tk.node = nd; tk.pad2 = 0; tk.count = min(TILE, count[nd] - p); tk.err = 0;
-        tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
-        tasks[task] = tk;
-    }
+    if ((p & (TILE - 1)) == 0) tasks[task] = make_task(nd, min(TILE, count[nd] - p), c0, k, ref.win, blk_off, NC);
 }
 
 // Level 0 needs no grouping: every sequence whose incoming status is OK stands on the root, so
@@ -711,7 +740,8 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
                                                     int32_t *__restrict__ status, const uint32_t *__restrict__ win,
                                                     LevelRec *__restrict__ cur, const int32_t *__restrict__ child_first,
                                                     const uint8_t *__restrict__ node_err, SeqRef *__restrict__ order,
-                                                    Task *__restrict__ tasks, int32_t *__restrict__ n_tasks) {
+                                                    Task *__restrict__ tasks, int32_t *__restrict__ n_tasks,
+                                                    const uint32_t *__restrict__ blk_off, int NC) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int st = status_in ? status_in[s] : 0;
@@ -726,12 +756,7 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
     ref.seq = st == 0 ? (int32_t)s : -1;
     ref.win = win[s];
     order[s] = ref;
-    if ((s & (TILE - 1)) == 0) {
-        Task tk;
-        tk.node = 0; tk.pad2 = 0; tk.count = (int32_t)min((int64_t)TILE, n - s); tk.err = 0;
-        tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
-        tasks[s / TILE] = tk;
-    }
+    if ((s & (TILE - 1)) == 0) tasks[s / TILE] = make_task(0, (int32_t)min((int64_t)TILE, n - s), c0, k, ref.win, blk_off, NC);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -766,6 +791,7 @@ struct WalkArgs {
     const uint4 *blocks;        // Entry[4] per block
     LevelRec *lvl;              // [n] this level's records
     int32_t *status;
+    const uint8_t *mfma_ok;     // [n_nodes] nodes whose tasks k_walk_mfma takes (null: none)
 };
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
@@ -800,8 +826,6 @@ __device__ __forceinline__ double masked_weight_v(const char *my_row, const uint
     return __hiloint2double((int)en.w & m, (int)en.z & m);
 }
 
-constexpr int ENT_PIECE = 48;     // coefficients a wave keeps in LDS at a time (768 B)
-
 // LDS-DMA (global_load_lds_*): each active lane's 4 / 16 bytes at `src` land in LDS at dst + lane * 4 / 16
 // (dst is wave-uniform) without passing through a VGPR.  hipcc counts these on vmcnt and drains them before
 // a __syncthreads(); a wave that reads its OWN DMA'd data without a barrier waits with dma_wait().
@@ -816,24 +840,30 @@ __device__ __forceinline__ void dma16(const uint4 *src, uint4 *dst) {
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void lds_reads_done() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// LDS of one walk workgroup: 20 KB (8 workgroups per CU), cut per task into the staged rows -- 64 rows of
+// `stride` words, stride = the staged width + 1 (odd: lane l reading word w is conflict-free) -- and, behind them,
+// NW equal wave-private pieces for coefficients, each used as two halves: the sibling a wave scores reads one
+// half while the coefficients of its next sibling land in the other.
+constexpr int WALK_LDS_WORDS = 5120;
+constexpr int RESULT_SLOT_ENTRIES = TILE * 12 / 16;   // a wave's result slot (64 doubles + 64 ints) in entries
+static_assert((WALK_LDS_WORDS - TILE * ROW_STRIDE) / NW / 4 >= RESULT_SLOT_ENTRIES, "result slot must fit a wave's piece");
+
 __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
-    __shared__ uint32_t s_rows[TILE * ROW_STRIDE];
-    // per wave 768 B: the coefficients of its sibling inside the slice while it scores, then its
-    // result slot (64 doubles + 64 ints) for the combine steps
-    __shared__ uint4 s_buf[NW][ENT_PIECE];
-    static_assert(ENT_PIECE * 16 >= TILE * 12, "result slot must fit the coefficient buffer");
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[WALK_LDS_WORDS];
 
     const int lane = threadIdx.x & 63;
     const int n_tasks = *as_const(a.n_tasks);
-    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[blockIdx.x];
+    const i32x16 tk = as_const(reinterpret_cast<const i32x16 *>(a.tasks))[blockIdx.x];
     // the task's slots of order[] sit at a fixed place: fetched together with the task record
     // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
     SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];
     if ((int)blockIdx.x >= n_tasks) return;
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int err = tk[3], c0 = tk[4], k = tk[5];
-    if (lane >= tk[2]) {
+    const int c0 = tk[2], k = tk[3];
+    if (k <= 1) return;   // never emitted: k_scatter / k_root_level settle such nodes themselves
+    if (a.mfma_ok && as_const(a.mfma_ok)[tk[0]]) return;   // k_walk_mfma's task
+    if (lane >= tk[1]) {
         me.seq = -1;
         me.win = 0xffffu;
     }
@@ -845,11 +875,6 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         r.prob = prob;
         a.lvl[seq] = r;
     };
-    uint4 *s_ent = s_buf[wave];
-    auto s_z = [&](int w) { return reinterpret_cast<double *>(s_buf[w]); };
-    auto s_c = [&](int w) { return reinterpret_cast<int *>(s_buf[w]) + 2 * TILE; };
-
-    if (k <= 1 || err) return;   // never emitted: k_scatter / k_root_level settle such nodes themselves
 #if STAG_ABL == 5
     if (seq >= 0) put(c0, 0.5);
     return;
@@ -868,12 +893,17 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     }
     const int cA = wave_min_i(lo);
     const int cB = min(wave_max_i(hi), a.NC);
-    const bool one_slice = cB - cA <= WCAP_CHUNKS;   // the usual case: staged once for all siblings
+    const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
+    const bool one_slice = wB - wA <= WCAP_CHUNKS;            // the usual case: staged once for all siblings
 
-    // Siblings are scored NW at a time ("pass"), one per wave.  (Splitting a sibling's chunks over
-    // the idle waves of a short pass was measured slower: the kernel is bound by instruction
-    // issue, not by the length of one wave's chain.)
-    //
+    // ---- LDS layout of this task
+    const int stride = one_slice ? (((wB - wA) * CHUNK_WORDS) | 1) : ROW_STRIDE;
+    const int ent_base_words = (TILE * stride + 3) & ~3;
+    const int piece = (WALK_LDS_WORDS - ent_base_words) / (4 * NW);      // entries per wave
+    const int half = min(piece >> 1, 64) & ~3;                          // entries per buffer: one DMA (one per lane) fills it
+    uint4 *const s_ent = reinterpret_cast<uint4 *>(s_mem + ent_base_words) + wave * piece;
+    uint32_t *const s_rows = s_mem;
+
     // CANONICAL SUMMATION.  A row's OWN window (from its own bits: the chunks in which it differs
     // from R0) fixes how its score is added up: z = (gappre[own_lo] + gapsuf[own_hi]) -- what R0
     // scores before and after that window, each a chain the host added up in a fixed order -- plus,
@@ -885,7 +915,6 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     // sibling rows tie exactly, so the first stored child wins as in classify.py:41.
     double best_p = -1.0;
     int best_c = -1;
-    const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;   // empty window: every chunk is "outside"
     // rows of the slice [sA, sB) -> LDS by LDS-DMA: one row per wave and step, lanes over words, no VGPR in
     // between.  The caller makes sure nobody still reads the previous slice (barrier) before, and drains the
     // DMA + barriers after.  Rows of absent lanes (seq < 0) and words past the slice keep stale data that
@@ -898,28 +927,29 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             for (int rr = 0; rr < TILE / NW; ++rr) {
                 // the row's sequence id as a scalar: its address is then computed once per wave
                 const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-                if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * ROW_STRIDE]);
+                if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
             }
         }
     };
-    // this wave's first ENT_PIECE coefficients of [e_lo, e_hi) -> its piece of LDS (wave-private)
-    auto fetch_ent = [&](uint32_t e_lo, uint32_t e_hi) {
-        if (lane < ENT_PIECE && e_lo + lane < e_hi) dma16(a.blocks + e_lo + lane, s_ent);
+    // up to `half` coefficients from e_lo on -> buffer `buf` of this wave's piece (wave-private)
+    auto fetch_ent = [&](uint32_t e_lo, uint32_t e_hi, int buf) {
+        if (lane < half && e_lo + lane < e_hi) dma16(a.blocks + e_lo + lane, s_ent + buf * half);
     };
-    // z += the sibling's chunk sums over the slice [sA, sB) (its first ENT_PIECE coefficients are in s_ent)
-    auto score_slice = [&](double &z, const uint32_t STAG_CONST *bo, uint32_t e_lo, uint32_t e_hi, int sA, int sB) {
+    // z += the sibling's chunk sums over the slice [sA, sB); its first `half` coefficients are in buffer `buf`
+    auto score_slice = [&](double &z, const uint32_t STAG_CONST *bo, uint32_t e_lo, uint32_t e_hi, int sA, int sB, int buf) {
         // which chunks of this slice lie in the lane's own window (bit i: chunk sA + i)
         const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
                                   ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
         // entry offsets are relative to the row; the slice starts at chunk sA
-        const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * ROW_STRIDE * 4 - sA * (CHUNK_WORDS * 4));
-        if (e_hi - e_lo <= (uint32_t)ENT_PIECE) {
-            // the usual case: every coefficient of the slice is in s_ent
+        const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * stride * 4 - sA * (CHUNK_WORDS * 4));
+        const uint4 *ent = s_ent + buf * half;
+        if (e_hi - e_lo <= (uint32_t)half) {
+            // the usual case: every coefficient of the slice is in the buffer
             for (int ch = sA; ch < sB; ++ch) {
                 const uint32_t e0 = bo[ch] * BLOCK_ENTRIES - e_lo, e1 = bo[ch + 1] * BLOCK_ENTRIES - e_lo;
                 double cs = 0.0;
                 for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                    const uint4 *pe = &s_ent[e];   // wave-uniform address: LDS broadcast
+                    const uint4 *pe = &ent[e];   // wave-uniform address: LDS broadcast
                     const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
                     cs += masked_weight_v(my_row, n0);
                     cs += masked_weight_v(my_row, n1);
@@ -929,25 +959,25 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
             }
         } else {
-            uint32_t piece = e_lo;   // first entry held in s_ent[wave]
+            uint32_t first = e_lo;   // first entry held in the buffer
             for (int ch = sA; ch < sB; ++ch) {
                 const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
                 double cs = 0.0;
                 for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
-                    if (e >= piece + ENT_PIECE) {   // more than 48 coefficients in the slice: next piece
-                        piece = e;
+                    if (e + BLOCK_ENTRIES > first + (uint32_t)half) {   // past the buffer: next stretch
+                        first = e;
                         lds_reads_done();
-                        fetch_ent(piece, e_hi);
+                        fetch_ent(first, e_hi, buf);
                         dma_wait();
                     }
-                    const uint4 *pe = &s_ent[e - piece];
+                    const uint4 *pe = &ent[e - first];
                     const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
                     cs += masked_weight_v(my_row, n0);
                     cs += masked_weight_v(my_row, n1);
                     cs += masked_weight_v(my_row, n2);
                     cs += masked_weight_v(my_row, n3);
                 }
-                z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;   // z is never -0.0: adding +0.0 is exact
+                z += ((own_mask >> (ch - sA)) & 1u) ? cs : 0.0;
             }
         }
     };
@@ -967,35 +997,66 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     };
 
     if (one_slice) {
-        // ---- the usual case: the window fits the staging buffer, staged once for all siblings
-        for (int pass0 = 0; pass0 < k; pass0 += NW) {
-            const bool active = pass0 + wave < k;
-            const int c = c0 + pass0 + wave;
-            const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
-            double z = 0.0;
+        // ---- the usual case: the window fits the staging buffer and is staged once for all siblings.  A wave
+        // scores the siblings wave, wave + NW, ...; while it scores one, the coefficients of its next one land in
+        // the other half of its piece, and the chunk offsets of the one after that are on their way.
+        const int n_mine = k > wave ? (k - wave + NW - 1) / NW : 0;
+        const bool windowed = wB > wA;
+        uint32_t e_lo = 0, e_hi = 0, ne_lo = 0, ne_hi = 0;     // this sibling's / the next sibling's coefficient range
+        double z = 0.0, nz = 0.0;
+        if (n_mine > 0) {
 #if STAG_ABL != 4
-            if (active) z = gap_consts(c);
+            z = gap_consts(c0 + wave);
 #endif
-            if (wB > wA) {
-                // this wave's coefficient range of the window: contiguous, chunk after chunk
-                uint32_t e_lo = 0, e_hi = 0;
-                if (active) { e_lo = bo[wA] * BLOCK_ENTRIES; e_hi = bo[wB] * BLOCK_ENTRIES; }
-                if (pass0 == 0) {
-#if STAG_ABL != 3
-                    stage_rows(wA, wB);
-#endif
-                    fetch_ent(e_lo, e_hi);       // in flight together with the rows
-                    __syncthreads();             // drains the DMA of every wave, then the barrier
+            if (windowed) {
+                if (tk[4] == wA && tk[5] == wB) {      // the hint fits: no lookup
+                    e_lo = (uint32_t)(wave == 0 ? tk[8] : wave == 1 ? tk[9] : wave == 2 ? tk[10] : tk[11]);
+                    e_hi = (uint32_t)(wave == 0 ? tk[12] : wave == 1 ? tk[13] : wave == 2 ? tk[14] : tk[15]);
                 } else {
-                    lds_reads_done();            // wave-private piece: the previous sibling's reads have returned
-                    fetch_ent(e_lo, e_hi);
-                    dma_wait();
+                    const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave) * a.NC;
+                    e_lo = bo[wA] * BLOCK_ENTRIES;
+                    e_hi = bo[wB] * BLOCK_ENTRIES;
                 }
-#if STAG_ABL != 1
-                if (active) score_slice(z, bo, e_lo, e_hi, wA, wB);
-#endif
             }
-            if (active) decide(z, c);
+        }
+        if (windowed) {
+#if STAG_ABL != 3
+            stage_rows(wA, wB);
+#endif
+            fetch_ent(e_lo, e_hi, 0);        // in flight together with the rows
+            if (n_mine > 1) {
+                const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave + NW) * a.NC;
+                ne_lo = bo[wA] * BLOCK_ENTRIES;
+                ne_hi = bo[wB] * BLOCK_ENTRIES;
+            }
+            __syncthreads();                 // drains the DMA of every wave, then the barrier
+        }
+        for (int i = 0; i < n_mine; ++i) {
+            const int c = c0 + wave + i * NW;
+            const uint32_t STAG_CONST *bo = blk_off + (size_t)c * a.NC;
+            uint32_t nn_lo = 0, nn_hi = 0;
+            if (i + 1 < n_mine) {
+#if STAG_ABL != 4
+                nz = gap_consts(c + NW);
+#endif
+                if (windowed) {
+                    fetch_ent(ne_lo, ne_hi, (i + 1) & 1);        // that half's last reader was sibling i - 1
+                    if (i + 2 < n_mine) {
+                        const uint32_t STAG_CONST *bo2 = blk_off + (size_t)(c + 2 * NW) * a.NC;
+                        nn_lo = bo2[wA] * BLOCK_ENTRIES;
+                        nn_hi = bo2[wB] * BLOCK_ENTRIES;
+                    }
+                }
+            }
+#if STAG_ABL != 1
+            if (windowed) score_slice(z, bo, e_lo, e_hi, wA, wB, i & 1);
+#endif
+            decide(z, c);
+            if (i + 1 < n_mine) {
+                lds_reads_done();
+                dma_wait();                  // the next sibling's coefficients have landed
+                z = nz; e_lo = ne_lo; e_hi = ne_hi; ne_lo = nn_lo; ne_hi = nn_hi;
+            }
         }
     } else {
         // ---- a window wider than the staging buffer: slice after slice; each slice is staged once for
@@ -1019,9 +1080,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                         const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
                         const uint32_t e_lo = bo[sA] * BLOCK_ENTRIES, e_hi = bo[sB] * BLOCK_ENTRIES;
                         lds_reads_done();            // wave-private piece, after the previous sibling's reads
-                        fetch_ent(e_lo, e_hi);
+                        fetch_ent(e_lo, e_hi, 0);
                         dma_wait();
-                        score_slice(zz[j], bo, e_lo, e_hi, sA, sB);
+                        score_slice(zz[j], bo, e_lo, e_hi, sA, sB, 0);
                     }
                 }
             }
@@ -1030,18 +1091,235 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 if (pg0 + j * NW + wave < k) decide(zz[j], c0 + pg0 + j * NW + wave);
         }
     }
-    // (the result slots below reuse each wave's own coefficient piece: LDS operations of one wave stay in order)
-    s_z(wave)[lane] = best_p;
-    s_c(wave)[lane] = best_c;
+    // the result slots reuse each wave's own coefficient piece: LDS operations of one wave stay in order, and no
+    // DMA is in flight any more
+    double *const my_z = reinterpret_cast<double *>(s_ent);
+    int *const my_c = reinterpret_cast<int *>(s_ent) + 2 * TILE;
+    my_z[lane] = best_p;
+    my_c[lane] = best_c;
     __syncthreads();
     if (wave == 0 && seq >= 0) {
         for (int w = 1; w < NW; ++w) {  // first maximum in stored order = largest p, then smallest id
-            const double p = s_z(w)[lane];
-            const int cc = s_c(w)[lane];
+            const double p = reinterpret_cast<const double *>(s_ent + w * piece)[lane];
+            const int cc = (reinterpret_cast<const int *>(s_ent + w * piece) + 2 * TILE)[lane];
             if (cc >= 0 && (p > best_p || (p == best_p && cc < best_c) || best_c < 0)) { best_p = p; best_c = cc; }
         }
         // best_c < 0: every probability was NaN, the reference stops here (classify.py:49)
         put(best_c, best_c >= 0 ? best_p : 0.0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// walk on the matrix cores: the same level for tasks of nodes that have the tables of stag_db_create's
+// "matrix-core tables".  For the task's 64 rows and its window, X[row][u] = bit of union feature u (one byte,
+// 0 or 1; 0 outside the row's OWN window) is built in LDS from the staged row words -- one bit extraction per
+// (row, union feature), shared by all k children, where the gather walk does one per (row, child, coefficient)
+// -- and  C[row][6 j + s] = sum_u X[row][u] * digit_s(w[j][u])  is computed by v_mfma_i32_16x16x64_i8.
+// z[row][j] = intercept + gappre[own_lo] + gapsuf[own_hi] + 2^-q * sum_s 256^s C[row][6 j + s]: integer
+// arithmetic up to the last step, so a score depends only on (row, node) -- never on the other rows of the
+// task -- and identical sibling rows tie exactly.  The coefficients are rounded to multiples of 2^-q (q >= 39
+// for |w| < 128): z is within n_coefficients * 2^-(q+1) of the exact sum, far inside the 1e-9 the path allows.
+// The child is chosen on z (clamped where the fp64 sigmoid saturates to 1.0 and where it vanishes to 0.0, so that
+// such siblings tie and the first stored one wins as in classify.py:41) and only the winner's probability is
+// computed; two children whose z differ but whose probabilities round to the same fp64 (possible for
+// z in ~[33, 36.7] only) are therefore not treated as a tie: a difference below 1 ulp of the probability.
+// ------------------------------------------------------------------------------------------
+struct MfmaArgs {
+    const uint32_t *pf_off;     // [n_nodes * NC + 1] first union feature of (parent, chunk), multiples of 16
+    const uint32_t *pfeat;      // descriptor per union feature: byte offset of the word in the row | bit << 16
+    const int8_t *dig;          // digit matrices
+    const uint64_t *dig_base;   // [n_nodes] where the parent's matrix starts
+    const uint32_t *dig_ld;     // [n_nodes] features of the parent = bytes per column
+    const double *qscale;       // [n_nodes] 2^-q
+    const uint8_t *mfma_ok;     // [n_nodes] 1: this kernel walks the node's tasks, 0: k_walk_level does
+};
+using v4i = __attribute__((ext_vector_type(4))) int;
+
+constexpr int MW_LDS_WORDS = 5632;                // 22,528 B: 7 workgroups per CU
+constexpr int MW_MAX_CB = MFMA_MAX_K / 2;         // column blocks of 16 (two children each)
+constexpr int MW_SCR_STRIDE = 33;                 // a wave's transposition scratch: [16 rows][32 columns + 1]
+constexpr double Z_SATURATED = 36.7368005696771;  // 53 ln 2: from here on 1 / (1 + exp(-z)) is 1.0 in fp64
+constexpr double Z_VANISHED = -709.782712893384;  // -ln(DBL_MAX): from here down exp(-z) overflows and the probability is 0.0
+__device__ __forceinline__ double clamp_z(double z) { return fmax(fmin(z, Z_SATURATED), Z_VANISHED); }
+
+// Workgroup = one task of <= 64 rows.  Together the four waves stage the row words (LDS-DMA) and build X
+// (lane = row, each wave a quarter of the features, descriptors in scalar registers); after that barrier every
+// wave is on its own: it multiplies ITS 16 rows with all column blocks, turns the result tile around in a
+// scratch that overlays its own rows of X, scores with lane = (row, child mod 4), reduces over the four lane
+// groups with DPP/LDS-free shuffles and writes its rows' level records.
+__global__ __launch_bounds__(NW * 64, 7) void k_walk_mfma(WalkArgs a, MfmaArgs m) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_mem[MW_LDS_WORDS];
+
+    const int lane = threadIdx.x & 63;
+    const int n_tasks = *as_const(a.n_tasks);
+    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[2 * blockIdx.x];
+    SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];     // lane = row of the task (staging, X)
+    if ((int)blockIdx.x >= n_tasks) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int node = tk[0], count = tk[1], c0 = tk[2], k = tk[3];
+    if (k <= 1 || !as_const(m.mfma_ok)[node]) return;          // the gather kernel's task
+    // what the matrix phase needs about the node: on its way while the windows are worked out
+    const uint32_t U = as_const(m.dig_ld)[node];
+    const uint32_t pf_first = as_const(m.pf_off)[(size_t)node * a.NC];
+    const int8_t *const dig = m.dig + as_const(m.dig_base)[node];
+    const double qs = as_const(m.qscale)[node];
+    if (lane >= count) {
+        me.seq = -1;
+        me.win = 0xffffu;
+    }
+    const int seq = me.seq;
+
+    // ---- windows (as in k_walk_level)
+    int lo = 0x7fff, hi = 0, own_lo = 0, own_hi = 0;
+    if (seq >= 0) {
+        const uint32_t wn = me.win;
+        const int l4 = (int)(wn & 0xffffu), h4 = (int)(wn >> 16);
+        if (h4 > l4) {
+            lo = own_lo = l4 >> 2;
+            hi = own_hi = min((h4 + 3) >> 2, a.NC);
+        }
+    }
+    const int cA = wave_min_i(lo);
+    const int cB = min(wave_max_i(hi), a.NC);
+    const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;
+    // do all rows of the task have the task's window?  (amplicon reads: yes)  Then no bit has to be masked.
+    const bool uniform_win = __ballot(seq >= 0 && (own_lo != wA || own_hi != wB)) == 0ull;
+
+    // ---- LDS: staged row words | X bytes (a wave's transposition scratch later overlays its own rows of X)
+    const int slice_chunks = min(wB - wA, WCAP_CHUNKS);
+    const int stride = (slice_chunks * CHUNK_WORDS) | 1;
+    const int rows_words = (TILE * stride + 3) & ~3;
+    const int XK = (MW_LDS_WORDS - rows_words) * 4 >= TILE * (128 + 16) ? 128 : 64;   // union features per X build
+    const int XS = XK + 16;                                                             // bytes per X row
+    static_assert(16 * MW_SCR_STRIDE * 4 <= 16 * (128 + 16), "scratch must fit 16 rows of the wide X");
+    static_assert(16 * MW_SCR_STRIDE <= 16 * ROW_STRIDE, "scratch must fit 16 staged rows of full width");
+    uint32_t *const s_rows = s_mem;
+    uint8_t *const s_x = reinterpret_cast<uint8_t *>(s_mem + rows_words);
+
+    const int ncb = (k + 1) >> 1;                              // column blocks of 16
+    const bool mine = 16 * wave < count;                       // does this wave have rows at all?
+    v4i acc[MW_MAX_CB];
+#pragma unroll
+    for (int i = 0; i < MW_MAX_CB; ++i) acc[i] = v4i{0, 0, 0, 0};
+
+    for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
+        const int sB = min(wB, sA + WCAP_CHUNKS);
+        if (sA != wA) __syncthreads();                     // the previous slice's X / rows have been read
+        {   // row words of the slice -> LDS (LDS-DMA; lanes over words, one row per wave and step)
+            const int w0 = sA * CHUNK_WORDS;
+            const int width = min(sB * CHUNK_WORDS, a.W) - w0;
+            if (lane < width) {
+#pragma unroll
+                for (int rr = 0; rr < TILE / NW; ++rr) {
+                    const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+                    if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
+                }
+            }
+        }
+        const uint32_t f0 = as_const(m.pf_off)[(size_t)node * a.NC + sA], f1 = as_const(m.pf_off)[(size_t)node * a.NC + sB];
+        // this lane's own chunks inside the slice (bit i: chunk sA + i)
+        const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
+                                  ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
+        const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * stride * 4 - sA * (CHUNK_WORDS * 4));
+        const int per_wave = XK / NW;                      // 32 or 16 features per wave and X build
+        for (uint32_t x0 = f0; x0 < f1; x0 += XK) {
+            // the descriptors of this wave's features: scalar loads, in flight across the barrier
+            const uint32_t u0 = x0 + wave * per_wave;
+            i32x16 d0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d1 = d0;
+            if (u0 < f1) d0 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0));
+            if (per_wave > 16 && u0 + 16 < f1) d1 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0 + 16));
+            __syncthreads();                               // rows landed (first build) / the previous X has been multiplied
+            // ---- X: lane = row; 16 features -> 16 bytes -> one 16-byte LDS store
+            auto build16 = [&](const i32x16 &d, bool valid, int at) {
+                uint32_t pk[4] = {0u, 0u, 0u, 0u};
+                if (valid) {                               // (f1 is a multiple of 16: a group is in or out)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const uint32_t desc = (uint32_t)d[i];
+                        const uint32_t word = *reinterpret_cast<const uint32_t *>(my_row + (desc & 0xffffu));
+                        uint32_t b = (word >> (desc >> 16)) & 1u;
+                        if (!uniform_win) b &= own_mask >> (((desc & 0xffffu) >> 6) - sA);
+                        pk[i >> 2] |= b << (8 * (i & 3));
+                    }
+                }
+                *reinterpret_cast<uint4 *>(s_x + lane * XS + at) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+            };
+            build16(d0, u0 < f1, wave * per_wave);
+            if (per_wave > 16) build16(d1, u0 + 16 < f1, wave * per_wave + 16);
+            __syncthreads();                               // X complete
+            // ---- C += X * digits for this wave's 16 rows, every column block
+            if (mine) {
+                const int nkb = min((int)((f1 - x0 + 63) >> 6), XK >> 6);
+                v4i afrag[2];
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb)
+                    if (kb < nkb)
+                        afrag[kb] = *reinterpret_cast<const v4i *>(s_x + (16 * wave + (lane & 15)) * XS + 64 * kb + 16 * (lane >> 4));
+                const int8_t *bcol = dig + (size_t)(lane & 15) * U + (x0 - pf_first) + 16 * (lane >> 4);
+#pragma unroll
+                for (int cb = 0; cb < MW_MAX_CB; ++cb) {
+                    if (cb < ncb) {
+#pragma unroll
+                        for (int kb = 0; kb < 2; ++kb)
+                            if (kb < nkb) {
+                                const v4i bfrag = *reinterpret_cast<const v4i *>(bcol + (size_t)(16 * cb) * U + 64 * kb);
+                                acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[kb], bfrag, acc[cb], 0, 0, 0);
+                            }
+                    }
+                }
+            }
+        }
+    }
+    if (!mine) return;
+
+    // ---- this wave's rows, lane = (row r, group g): group g scores the children g, g + 4, ... of the node
+    const int r = lane & 15, g = lane >> 4;
+    const int my_slot = 16 * wave + r;
+    const int myseq = __shfl(seq, my_slot);
+    const int r_lo = __shfl(own_lo, my_slot), r_hi = __shfl(own_hi, my_slot);
+    // the transposition scratch overlays this wave's own 16 rows of X (only this wave has read them, and its MFMAs
+    // are done with them) -- or, when X is the narrow one (which it is only under full-width staged rows), this
+    // wave's 16 staged rows: every wave passed the last "X complete" barrier, nobody reads rows or writes X any more
+    int *const scr = XK == 128 ? reinterpret_cast<int *>(s_x + (size_t)16 * wave * XS)
+                               : reinterpret_cast<int *>(s_rows + (size_t)16 * wave * stride);
+    double best_z = 0.0, best_raw = 0.0;
+    int best_c = -1;
+#pragma unroll
+    for (int rd = 0; rd < MW_MAX_CB / 2; ++rd) {           // a round = 2 column blocks = 4 children
+        if (4 * rd < k) {
+            // C/D layout of the 16x16 tile: column = lane & 15, rows 4 (lane >> 4) .. + 3 in the 4 registers
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    scr[(4 * (lane >> 4) + q) * MW_SCR_STRIDE + 16 * h + (lane & 15)] = acc[2 * rd + h][q];
+            const int j = 4 * rd + g;                      // this lane's child in the round
+            const int *cr = scr + r * MW_SCR_STRIDE + 8 * g;
+            double v = (double)cr[5];
+#pragma unroll
+            for (int sl = 4; sl >= 0; --sl) v = v * 256.0 + (double)cr[sl];
+            if (j < k) {
+                const int c = c0 + j;
+                const size_t base = (size_t)c * (a.NC + 1);
+                const double z = ((a.gappre[base + r_lo] + a.gapsuf[base + r_hi]) + v * qs) + a.intercept[c];
+                const double zc = clamp_z(z);
+                if (best_c < 0 || zc > best_z) { best_z = zc; best_raw = z; best_c = c; }   // strict '>' in stored order
+            }
+        }
+    }
+    // ---- first maximum in stored order over the four lane groups of a row: largest z, then smallest child
+#pragma unroll
+    for (int step = 16; step <= 32; step <<= 1) {
+        const double oz = __shfl_xor(best_z, step), oraw = __shfl_xor(best_raw, step);
+        const int oc = __shfl_xor(best_c, step);
+        if (oc >= 0 && (best_c < 0 || oz > best_z || (oz == best_z && oc < best_c))) { best_z = oz; best_raw = oraw; best_c = oc; }
+    }
+    if (g == 0 && myseq >= 0) {
+        LevelRec rec;
+        rec.node = best_c;
+        rec.pad = 0;
+        rec.prob = sigmoid(best_raw);
+        a.lvl[myseq] = rec;
     }
 }
 

@@ -190,3 +190,26 @@ def test_wide_levels_use_every_grouping_path():
         assert np.array_equal(out["selected"], res.selected)
         res2 = run(db, text, offs, np.arange(n)[::-1].copy())
         assert np.array_equal(res2.path_node, res.path_node[::-1]) and np.array_equal(res2.path_prob, res.path_prob[::-1])
+
+
+def test_matrix_core_walk_equals_gather_walk_on_c2(c2, monkeypatch):
+    """The two walk kernels on 200k C2 reads: same lineage for every read, probabilities within 1e-9 of each
+    other (the matrix-core walk rounds coefficients to multiples of 2^-q, q >= 39), and the matrix-core walk is
+    bit-identical under shuffling (integer sums do not depend on the order of anything)."""
+    wl, text, offs, leaf = c2
+    t = wl.tables
+    idx = np.arange(0, N, 5)
+    monkeypatch.setenv("STAG_WALK", "gather")
+    with Database(t) as db:
+        ref = run(db, text, offs, idx)
+    monkeypatch.setenv("STAG_WALK", "auto")
+    with Database(t) as db:
+        got = run(db, text, offs, idx)
+        perm = np.random.default_rng(3).permutation(len(idx))
+        again = run(db, text, offs, idx[perm])
+    assert np.array_equal(got.path_node, ref.path_node) and np.array_equal(got.selected, ref.selected)
+    np.testing.assert_allclose(got.path_prob, ref.path_prob, rtol=1e-9, atol=0)
+    np.testing.assert_allclose(got.level_prob, ref.level_prob, rtol=1e-9, atol=0)
+    assert not np.array_equal(got.path_prob, ref.path_prob)          # (they are different kernels)
+    for f in ("path_node", "path_prob", "level_prob", "selected"):
+        assert np.array_equal(getattr(again, f), getattr(got, f)[perm]), f

@@ -16,6 +16,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
+@pytest.fixture(autouse=True, params=["auto", "gather"])
+def walk_kernel(request, monkeypatch):
+    """Every test of this file runs twice: with the walk the library picks per node (the matrix-core kernel
+    k_walk_mfma wherever a node has its tables) and with STAG_WALK=gather, which sends every node through the
+    gather kernel k_walk_level (read by stag_db_create)."""
+    monkeypatch.setenv("STAG_WALK", request.param)
+    return request.param
+
+
 def encode_raw(strings, L):
     text, offs = tables.pack_text(strings)
     n = len(strings)
