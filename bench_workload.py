@@ -78,7 +78,11 @@ def make_db(seed, ncol, level_sizes, nnz_frac=0.02, name="synthetic"):
                 keep = rng.choice(len(f), size=nnz, replace=False)
                 f, w = f[keep], w[keep]
             elif len(f) < nnz:                                # fill with weak, uninformative features
-                extra = np.setdiff1d(rng.choice(L, size=2 * (nnz - len(f)) + 8, replace=False), f)[: nnz - len(f)]
+                pool = rng.choice(L, size=min(L, 2 * (nnz - len(f)) + 8), replace=False)
+                extra = np.setdiff1d(pool, f)
+                if len(extra) < nnz - len(f):                 # (dense rows: take whatever is left)
+                    extra = np.setdiff1d(np.arange(L), f)
+                extra = extra[: nnz - len(f)]
                 f = np.concatenate([f, extra])
                 w = np.concatenate([w, rng.normal(0, 0.2, size=len(extra))])
             order = np.argsort(f, kind="stable")

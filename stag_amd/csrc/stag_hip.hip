@@ -137,6 +137,7 @@ struct stag_db {
     DevBuf<uint8_t> mfma_ok;
     std::vector<uint8_t> level_has_mfma, level_has_gather;   // per level: are there tasks for either kernel?
     int walk_mode = 0;                                         // 0 auto, 1 gather only (STAG_WALK=gather)
+    DevBuf<unsigned long long> dbg;                            // phase stamps of STAG_ABL == 10 builds
     DevBuf<uint8_t> text, gene_text, bt_text;
     DevBuf<int64_t> offs, gene_offs, bt_begin, bt_end;
     DevBuf<int32_t> bt_status;
@@ -300,6 +301,9 @@ int reserve_walk(stag_db *db, int64_t n) {
     if ((rc = db->count.reserve(db->n_nodes))) return rc;
     if ((rc = db->task_off.reserve(db->n_nodes))) return rc;
     if ((rc = db->n_tasks.reserve(std::max(db->max_depth, 1)))) return rc;
+#if STAG_ABL == 10
+    if (!db->dbg.p) { if ((rc = db->dbg.reserve(4096 * 16))) return rc; (void)hipMemset(db->dbg.p, 0, 4096 * 16 * sizeof(unsigned long long)); }
+#endif
     if ((rc = reserve_results(db, n))) return rc;
     db->cap_n = std::max(db->cap_n, n);
     return STAG_OK;
@@ -349,13 +353,17 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
     }
     int rc;
     if ((rc = launch_check("k_init_status"))) return rc;
+    HintTables hints;
+    hints.blk_off = db->blk_off.p; hints.NC = db->nchunks;
+    hints.mfma_ok = db->walk_mode != 1 ? db->mfma_ok.p : nullptr;
+    hints.pf_off = db->pf_off.p; hints.dig_base = db->dig_base.p; hints.dig_ld = db->dig_ld.p; hints.qscale = db->qscale.p;
     for (int d = 0; d < db->max_depth; ++d) {
         const int lo = db->level_start[d], hi = db->level_start[d + 1];
         LevelRec *cur = wk.lvl + (size_t)d * n;
         if (d == 0) {
             Prof p(db, st, 2, wk.prof);
             hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, wk.win, cur,
-                               db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks, db->blk_off.p, db->nchunks);
+                               db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks, hints);
         } else {
             Prof p(db, st, 2, wk.prof);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
@@ -364,8 +372,7 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
             hipLaunchKernelGGL(k_scan_level, dim3(1), dim3(1024), 0, st, lo, hi, wk.count, db->child_first.p,
                                db->node_err.p, wk.task_off, wk.n_tasks + d);
             hipLaunchKernelGGL(k_scatter, dim3(g256), dim3(256), 0, st, n, lo, hi, wk.node, wk.pos, wk.count,
-                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks, cur, o.status,
-                               db->blk_off.p, db->nchunks);
+                               wk.task_off, db->child_first.p, db->node_err.p, wk.win, wk.order, wk.tasks, cur, o.status, hints);
         }
         if ((rc = launch_check("grouping kernels"))) return rc;
         WalkArgs a;
@@ -375,6 +382,7 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         a.blk_off = db->blk_off.p; a.blocks = db->blocks.p;
         a.lvl = cur; a.status = o.status;
         a.gappre = db->gappre.p; a.gapsuf = db->gapsuf.p;
+        a.dbg = db->dbg.p;
         const int64_t max_tasks = std::min<int64_t>(n, n / TILE + (hi - lo) + 1);
         // nodes with matrix-core tables are walked by k_walk_mfma, the others (children beyond its column blocks,
         // coefficients that are not finite, STAG_WALK=gather) by k_walk_level; a level launches what it has
@@ -583,14 +591,22 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
     std::vector<double> qscale(n, 0.0);
     std::vector<uint8_t> mfma_ok(n, 0);
     std::vector<int8_t> dig;
+    // STAG_WALK: "gather" = every node through k_walk_level, "mfma" = every node that can through k_walk_mfma,
+    // otherwise (auto) k_walk_mfma for the nodes whose rows are dense enough for it to win (MFMA_MIN_DENSITY,
+    // measured: profiles/r2_walk_density.md)
     const char *walk_env = getenv("STAG_WALK");
-    db->walk_mode = walk_env && !strcmp(walk_env, "gather") ? 1 : 0;
+    db->walk_mode = walk_env && !strcmp(walk_env, "gather") ? 1 : walk_env && !strcmp(walk_env, "mfma") ? 2 : 0;
     {
         std::vector<int32_t> ufeat;                    // union features of one chunk
         std::vector<size_t> at;                        // per child: next coefficient
         for (int p = 0; p < n; ++p) {
             const int c0 = t->child_first[p], k = t->child_first[p + 1] - c0;
-            bool ok = db->walk_mode == 0 && k >= 2 && k <= MFMA_MAX_K && !node_err[p];
+            bool ok = db->walk_mode != 1 && k >= 2 && k <= MFMA_MAX_K && !node_err[p];
+            if (ok && db->walk_mode == 0) {      // auto: only where the children's rows are dense
+                int64_t nnz = 0;
+                for (int c = c0; c < c0 + k; ++c) nnz += t->row_off[c + 1] - t->row_off[c];
+                ok = (double)nnz >= MFMA_MIN_DENSITY * (double)k * (double)t->n_features;
+            }
             double wmax = 0.0;
             if (ok)
                 for (int c = c0; c < c0 + k && ok; ++c) {
@@ -716,6 +732,21 @@ int stag_db_create(const stag_tables_t *t, int32_t device, stag_db_t **out) {
 void stag_db_destroy(stag_db_t *db) {
     if (!db) return;
     (void)hipSetDevice(db->device);
+#if STAG_ABL == 10
+    {
+        unsigned long long h[16] = {};
+        std::vector<unsigned long long> all(4096 * 16, 0);
+        (void)hipDeviceSynchronize();
+        if (db->dbg.p && hipMemcpy(all.data(), db->dbg.p, all.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t i = 0; i < all.size(); ++i) h[i & 15] += all[i];
+        }
+        if (h[15]) {
+            fprintf(stderr, "k_walk_mfma phases, cycles per workgroup over %llu workgroups:", h[15]);
+            for (int i = 0; i < 8; ++i) fprintf(stderr, " [%d] %.0f", i, (double)h[i] / (double)h[15]);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     db->free_all();
     delete db;
 }

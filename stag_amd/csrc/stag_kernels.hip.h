@@ -33,6 +33,7 @@ constexpr int WCAP_CHUNKS = 4;    // chunks of a row staged in LDS at a time (80
 constexpr int ROW_STRIDE = WCAP_CHUNKS * CHUNK_WORDS + 1;  // odd: lane l reads word w at l*ROW_STRIDE+w, conflict-free
 constexpr int BLOCK_ENTRIES = 4;  // coefficient lists are padded to 4 entries per (row, chunk)
 constexpr int MFMA_SLICES = 6;    // signed base-256 digits per coefficient in the matrix-core walk
+constexpr double MFMA_MIN_DENSITY = 0.05;   // non-zero fraction of the children's rows from which k_walk_mfma is chosen
 constexpr int MFMA_MAX_K = 16;    // children per node it handles: two per block of 16 columns, 8 blocks
 static_assert(WCAP_CHUNKS * CHUNK_WORDS == 64, "a staged slice is one dword per lane and row: all 64 lanes store into a row of ROW_STRIDE words");
 
@@ -50,18 +51,27 @@ __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
     return (const T STAG_CONST *)(uintptr_t)p;
 }
 
-struct Task {       // 64 bytes: one s_load_dwordx16 tells a workgroup everything about its task
+struct Task {       // 128 bytes; a walk kernel reads the first 32 and its own 32 with two scalar loads
     int32_t node, count;
     int32_t c0, k;                     // children of node: ids c0 .. c0+k-1, k >= 2 (other nodes get no task)
-    // HINT: where the coefficients of the first NW siblings (one per wave) sit for the window [hA, hB) (chunks) of
-    // the task's first sequence -- looked up by the grouping kernel, where a million threads hide the two
-    // dependent loads, instead of by every wave of the walk.  Tasks are mostly made of rows with the same
-    // window (amplicon reads); when the union of the task's windows differs, the walk looks them up itself.
+    // HINT: everything a walk kernel would otherwise have to look up -- in loads that depend on each other -- before
+    // it can fetch coefficients, for the window [hA, hB) (chunks) of the task's first sequence.  The grouping kernel
+    // looks it up, where a million threads hide those loads; the walk then issues all its fetches right after this
+    // record arrives.  Tasks are mostly made of rows with the same window (amplicon reads); when the union of the
+    // task's windows differs, the walk does the lookups itself.
     int32_t hA, hB;
-    int32_t pad0, pad1;
-    uint32_t e_lo[4], e_hi[4];         // in entries
+    int32_t mfma, pad1;                // mfma: the node has matrix-core tables (k_walk_mfma's task)
+    // k_walk_level: where the coefficients of the first NW siblings (one per wave) sit for the hint window, in entries
+    uint32_t e_lo[4], e_hi[4];
+    // k_walk_mfma: the node's digit matrix and the hint window's union features
+    uint64_t dig_at;                   // byte offset in dig of column 0's digit of the window's first feature
+    uint32_t U;                        // bytes per column
+    uint32_t f0, nf;                   // first union feature of the window (index into pfeat) and their number
+    uint32_t pad2;
+    double qscale;
+    int32_t pad3[8];
 };
-static_assert(sizeof(Task) == 64, "one s_load_dwordx16");
+static_assert(sizeof(Task) == 128, "two aligned scalar loads per kernel");
 // order[]: a sequence id and its R0 window, so the walk needs one load, not two.  Task t owns the
 // 64 slots order[64 t .. 64 t + 63] (the first `count` are filled): the walk can fetch its task
 // record and its sequences at the same time instead of one after the other.
@@ -685,24 +695,48 @@ __device__ __forceinline__ void settle_trivial(int c0, int k, int err, int64_t s
     cur[s] = r;
 }
 
+// Tables a grouping kernel needs to resolve a task's hints.
+struct HintTables {
+    const uint32_t *blk_off;    // gather walk: [n_nodes * NC + 1]
+    const uint8_t *mfma_ok;     // [n_nodes] (null: no matrix-core tables)
+    const uint32_t *pf_off;
+    const uint64_t *dig_base;
+    const uint32_t *dig_ld;
+    const double *qscale;
+    int NC;
+};
+
 // The task record of <= 64 sequences of node nd, with the hint (see Task) taken from one of its sequences' window.
-__device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint32_t win, const uint32_t *__restrict__ blk_off,
-                                          int NC) {
+__device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint32_t win, const HintTables &h) {
     Task tk;
-    tk.node = nd; tk.count = count; tk.c0 = c0; tk.k = k; tk.pad0 = 0; tk.pad1 = 0;
+    tk.node = nd; tk.count = count; tk.c0 = c0; tk.k = k; tk.pad1 = 0; tk.pad2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) tk.pad3[i] = 0;
     const int l4 = (int)(win & 0xffffu), h4 = (int)(win >> 16);
     int hA = 0, hB = 0;
-    if (h4 > l4) { hA = l4 >> 2; hB = min((h4 + 3) >> 2, NC); }
+    if (h4 > l4) { hA = l4 >> 2; hB = min((h4 + 3) >> 2, h.NC); }
     tk.hA = hA; tk.hB = hB;
+    const bool mfma = h.mfma_ok && h.mfma_ok[nd];
+    tk.mfma = mfma ? 1 : 0;
+    tk.dig_at = 0; tk.U = 0; tk.f0 = 0; tk.nf = 0; tk.qscale = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        uint32_t e0 = 0, e1 = 0;
-        if (j < k && hB > hA) {
-            const uint32_t *bo = blk_off + (size_t)(c0 + j) * NC;
-            e0 = bo[hA] * BLOCK_ENTRIES;
-            e1 = bo[hB] * BLOCK_ENTRIES;
-        }
-        tk.e_lo[j] = e0; tk.e_hi[j] = e1;
+    for (int j = 0; j < 4; ++j) { tk.e_lo[j] = 0; tk.e_hi[j] = 0; }
+    if (mfma) {
+        const uint32_t *po = h.pf_off + (size_t)nd * h.NC;
+        const uint32_t first = po[0], f0 = po[hA], f1 = po[hB];
+        tk.U = h.dig_ld[nd];
+        tk.f0 = f0;
+        tk.nf = f1 - f0;
+        tk.dig_at = h.dig_base[nd] + (f0 - first);
+        tk.qscale = h.qscale[nd];
+    } else if (hB > hA) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < k) {
+                const uint32_t *bo = h.blk_off + (size_t)(c0 + j) * h.NC;
+                tk.e_lo[j] = bo[hA] * BLOCK_ENTRIES;
+                tk.e_hi[j] = bo[hB] * BLOCK_ENTRIES;
+            }
     }
     return tk;
 }
@@ -714,7 +748,7 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
                                                  const uint8_t *__restrict__ node_err, const uint32_t *__restrict__ win,
                                                  SeqRef *__restrict__ order, Task *__restrict__ tasks,
                                                  LevelRec *__restrict__ cur, int32_t *__restrict__ status,
-                                                 const uint32_t *__restrict__ blk_off, int NC) {
+                                                 HintTables hints) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int nd = node[s];
@@ -730,7 +764,7 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
     ref.seq = (int32_t)s;
     ref.win = win[s];
     order[(size_t)task * TILE + (p & (TILE - 1))] = ref;
-    if ((p & (TILE - 1)) == 0) tasks[task] = make_task(nd, min(TILE, count[nd] - p), c0, k, ref.win, blk_off, NC);
+    if ((p & (TILE - 1)) == 0) tasks[task] = make_task(nd, min(TILE, count[nd] - p), c0, k, ref.win, hints);
 }
 
 // Level 0 needs no grouping: every sequence whose incoming status is OK stands on the root, so
@@ -741,7 +775,7 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
                                                     LevelRec *__restrict__ cur, const int32_t *__restrict__ child_first,
                                                     const uint8_t *__restrict__ node_err, SeqRef *__restrict__ order,
                                                     Task *__restrict__ tasks, int32_t *__restrict__ n_tasks,
-                                                    const uint32_t *__restrict__ blk_off, int NC) {
+                                                    HintTables hints) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
     const int st = status_in ? status_in[s] : 0;
@@ -756,7 +790,7 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
     ref.seq = st == 0 ? (int32_t)s : -1;
     ref.win = win[s];
     order[s] = ref;
-    if ((s & (TILE - 1)) == 0) tasks[s / TILE] = make_task(0, (int32_t)min((int64_t)TILE, n - s), c0, k, ref.win, blk_off, NC);
+    if ((s & (TILE - 1)) == 0) tasks[s / TILE] = make_task(0, (int32_t)min((int64_t)TILE, n - s), c0, k, ref.win, hints);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -792,7 +826,14 @@ struct WalkArgs {
     LevelRec *lvl;              // [n] this level's records
     int32_t *status;
     const uint8_t *mfma_ok;     // [n_nodes] nodes whose tasks k_walk_mfma takes (null: none)
+    unsigned long long *dbg;    // STAG_ABL == 10 builds: cycles per phase, summed over workgroups (else unused)
 };
+#if STAG_ABL == 10
+#define STAG_STAMP(i) do { const unsigned long long now_ = __builtin_readcyclecounter(); \
+                           phase_[i] += now_ - stamp_; stamp_ = now_; } while (0)
+#else
+#define STAG_STAMP(i) do { } while (0)
+#endif
 
 __device__ __forceinline__ double sigmoid(double z) { return 1.0 / (1.0 + exp(-z)); }
 
@@ -853,7 +894,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int n_tasks = *as_const(a.n_tasks);
-    const i32x16 tk = as_const(reinterpret_cast<const i32x16 *>(a.tasks))[blockIdx.x];
+    const i32x16 tk = as_const(reinterpret_cast<const i32x16 *>(a.tasks))[2 * blockIdx.x];
     // the task's slots of order[] sit at a fixed place: fetched together with the task record
     // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
     SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];
@@ -862,7 +903,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = tk[2], k = tk[3];
     if (k <= 1) return;   // never emitted: k_scatter / k_root_level settle such nodes themselves
-    if (a.mfma_ok && as_const(a.mfma_ok)[tk[0]]) return;   // k_walk_mfma's task
+    if (tk[6]) return;   // k_walk_mfma's task
     if (lane >= tk[1]) {
         me.seq = -1;
         me.win = 0xffffu;
@@ -1119,10 +1160,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 // arithmetic up to the last step, so a score depends only on (row, node) -- never on the other rows of the
 // task -- and identical sibling rows tie exactly.  The coefficients are rounded to multiples of 2^-q (q >= 39
 // for |w| < 128): z is within n_coefficients * 2^-(q+1) of the exact sum, far inside the 1e-9 the path allows.
-// The child is chosen on z (clamped where the fp64 sigmoid saturates to 1.0 and where it vanishes to 0.0, so that
-// such siblings tie and the first stored one wins as in classify.py:41) and only the winner's probability is
-// computed; two children whose z differ but whose probabilities round to the same fp64 (possible for
-// z in ~[33, 36.7] only) are therefore not treated as a tie: a difference below 1 ulp of the probability.
+// The child is chosen by comparing scores where that is the same as comparing probabilities, and probabilities
+// where it is not (beats()); only then, and for the winner, a sigmoid is computed.
 // ------------------------------------------------------------------------------------------
 struct MfmaArgs {
     const uint32_t *pf_off;     // [n_nodes * NC + 1] first union feature of (parent, chunk), multiples of 16
@@ -1135,34 +1174,47 @@ struct MfmaArgs {
 };
 using v4i = __attribute__((ext_vector_type(4))) int;
 
-constexpr int MW_LDS_WORDS = 5632;                // 22,528 B: 7 workgroups per CU
-constexpr int MW_MAX_CB = MFMA_MAX_K / 2;         // column blocks of 16 (two children each)
-constexpr int MW_SCR_STRIDE = 33;                 // a wave's transposition scratch: [16 rows][32 columns + 1]
-constexpr double Z_SATURATED = 36.7368005696771;  // 53 ln 2: from here on 1 / (1 + exp(-z)) is 1.0 in fp64
-constexpr double Z_VANISHED = -709.782712893384;  // -ln(DBL_MAX): from here down exp(-z) overflows and the probability is 0.0
-__device__ __forceinline__ double clamp_z(double z) { return fmax(fmin(z, Z_SATURATED), Z_VANISHED); }
+constexpr int MW_LDS_WORDS = 5632;                // 22,528 B
+constexpr int MW_C_STRIDE = 65;                   // C tile of a round: [64 rows][4 column blocks = 8 children] + 1
+// Is sigmoid(z) > sigmoid(zb) as fp64 numbers (what classify.py:41 compares)?  The sigmoid is increasing, so the
+// scores themselves decide -- except where different scores round to the same probability: towards 1.0 (two scores
+// above 20 can share a probability; from 36.74 on it is exactly 1.0) and where exp(-z) overflows (probability 0.0
+// below -709.78).  There the two probabilities are computed and compared, so that such siblings tie and the first
+// stored one wins, as in the reference.  (Between those bounds two scores collide only when they differ by less
+// than 5e-8, i.e. when the probabilities agree to 16 digits.)
+constexpr double Z_EXACT_ABOVE = 20.0, Z_EXACT_BELOW = -700.0;
+__device__ __forceinline__ bool beats(double z, double zb) {
+    const double top = fmax(z, zb);
+    if (top < Z_EXACT_ABOVE && top > Z_EXACT_BELOW) return z > zb;
+    return sigmoid(z) > sigmoid(zb);
+}
+static_assert(TILE * MW_C_STRIDE <= MW_LDS_WORDS, "the C tile overlays rows + X");
+static_assert(MFMA_MAX_K <= 16, "two rounds of 8 children, one column block per wave and round");
 
-// Workgroup = one task of <= 64 rows.  Together the four waves stage the row words (LDS-DMA) and build X
-// (lane = row, each wave a quarter of the features, descriptors in scalar registers); after that barrier every
-// wave is on its own: it multiplies ITS 16 rows with all column blocks, turns the result tile around in a
-// scratch that overlays its own rows of X, scores with lane = (row, child mod 4), reduces over the four lane
-// groups with DPP/LDS-free shuffles and writes its rows' level records.
-__global__ __launch_bounds__(NW * 64, 7) void k_walk_mfma(WalkArgs a, MfmaArgs m) {
+// Workgroup = one task of <= 64 rows, 4 waves.
+//   1. every fetch the task needs is issued as soon as its record is there (the record carries the hint, see Task):
+//      row words by LDS-DMA, this wave's feature descriptors (scalar), its digit fragments and the constants of the
+//      children it will score;
+//   2. X: lane = row, each wave a quarter of the features (descriptors in scalar registers), 16 bytes per store;
+//   3. C = X * digits: wave w multiplies all 64 rows with column blocks w (children 2w, 2w+1) and w + 4;
+//   4. through a C tile in LDS (it overlays rows and X) to lane = (row, group): wave w scores ITS 16 rows, lane group
+//      g the children g, g + 4, ...; the four groups are reduced with shuffles; the wave writes its rows' records.
+__global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m) {
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[MW_LDS_WORDS];
 
     const int lane = threadIdx.x & 63;
+#if STAG_ABL == 10
+    unsigned long long phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_ = __builtin_readcyclecounter();
+#endif
     const int n_tasks = *as_const(a.n_tasks);
-    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[2 * blockIdx.x];
+    const i32x8 t0 = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x];
+    const i32x8 t2 = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x + 2];
     SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];     // lane = row of the task (staging, X)
     if ((int)blockIdx.x >= n_tasks) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int node = tk[0], count = tk[1], c0 = tk[2], k = tk[3];
-    if (k <= 1 || !as_const(m.mfma_ok)[node]) return;          // the gather kernel's task
-    // what the matrix phase needs about the node: on its way while the windows are worked out
-    const uint32_t U = as_const(m.dig_ld)[node];
-    const uint32_t pf_first = as_const(m.pf_off)[(size_t)node * a.NC];
-    const int8_t *const dig = m.dig + as_const(m.dig_base)[node];
-    const double qs = as_const(m.qscale)[node];
+    const int node = t0[0], count = t0[1], c0 = t0[2], k = t0[3];
+    if (k <= 1 || !t0[6]) return;                              // the gather kernel's task
     if (lane >= count) {
         me.seq = -1;
         me.win = 0xffffu;
@@ -1184,135 +1236,200 @@ __global__ __launch_bounds__(NW * 64, 7) void k_walk_mfma(WalkArgs a, MfmaArgs m
     const int wA = cB > cA ? cA : 0, wB = cB > cA ? cB : 0;
     // do all rows of the task have the task's window?  (amplicon reads: yes)  Then no bit has to be masked.
     const bool uniform_win = __ballot(seq >= 0 && (own_lo != wA || own_hi != wB)) == 0ull;
+#if STAG_ABL == 6
+    if (wave == 0 && seq >= 0) { LevelRec rec; rec.node = c0; rec.pad = wA + wB; rec.prob = 0.5; a.lvl[seq] = rec; }
+    return;
+#endif
+    STAG_STAMP(0);   // task record + order arrived, windows known
+    // does the hint describe this window?  Otherwise (rows with other windows joined the task, or the window is
+    // staged slice by slice) the lookups happen here, one after the other.
+    const bool hinted = wA == t0[4] && wB == t0[5] && wB - wA <= WCAP_CHUNKS;
+    uint32_t U = (uint32_t)t2[2];
+    double qs = __hiloint2double(t2[7], t2[6]);
+    const int8_t *dig_node = nullptr;                           // column 0, first feature of the node
+    uint32_t pf_first = 0;
+    if (!hinted) {
+        U = as_const(m.dig_ld)[node];
+        qs = as_const(m.qscale)[node];
+        dig_node = m.dig + as_const(m.dig_base)[node];
+        pf_first = as_const(m.pf_off)[(size_t)node * a.NC];
+    }
 
-    // ---- LDS: staged row words | X bytes (a wave's transposition scratch later overlays its own rows of X)
+    // ---- LDS: staged row words | X bytes; the C tile later overlays both
     const int slice_chunks = min(wB - wA, WCAP_CHUNKS);
     const int stride = (slice_chunks * CHUNK_WORDS) | 1;
     const int rows_words = (TILE * stride + 3) & ~3;
     const int XK = (MW_LDS_WORDS - rows_words) * 4 >= TILE * (128 + 16) ? 128 : 64;   // union features per X build
     const int XS = XK + 16;                                                             // bytes per X row
-    static_assert(16 * MW_SCR_STRIDE * 4 <= 16 * (128 + 16), "scratch must fit 16 rows of the wide X");
-    static_assert(16 * MW_SCR_STRIDE <= 16 * ROW_STRIDE, "scratch must fit 16 staged rows of full width");
     uint32_t *const s_rows = s_mem;
     uint8_t *const s_x = reinterpret_cast<uint8_t *>(s_mem + rows_words);
+    const int per_wave = XK / NW;                              // 32 or 16 features per wave and X build
 
-    const int ncb = (k + 1) >> 1;                              // column blocks of 16
-    const bool mine = 16 * wave < count;                       // does this wave have rows at all?
-    v4i acc[MW_MAX_CB];
-#pragma unroll
-    for (int i = 0; i < MW_MAX_CB; ++i) acc[i] = v4i{0, 0, 0, 0};
-
-    for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
-        const int sB = min(wB, sA + WCAP_CHUNKS);
-        if (sA != wA) __syncthreads();                     // the previous slice's X / rows have been read
-        {   // row words of the slice -> LDS (LDS-DMA; lanes over words, one row per wave and step)
-            const int w0 = sA * CHUNK_WORDS;
-            const int width = min(sB * CHUNK_WORDS, a.W) - w0;
-            if (lane < width) {
-#pragma unroll
-                for (int rr = 0; rr < TILE / NW; ++rr) {
-                    const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-                    if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
-                }
-            }
-        }
-        const uint32_t f0 = as_const(m.pf_off)[(size_t)node * a.NC + sA], f1 = as_const(m.pf_off)[(size_t)node * a.NC + sB];
-        // this lane's own chunks inside the slice (bit i: chunk sA + i)
-        const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
-                                  ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
-        const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * stride * 4 - sA * (CHUNK_WORDS * 4));
-        const int per_wave = XK / NW;                      // 32 or 16 features per wave and X build
-        for (uint32_t x0 = f0; x0 < f1; x0 += XK) {
-            // the descriptors of this wave's features: scalar loads, in flight across the barrier
-            const uint32_t u0 = x0 + wave * per_wave;
-            i32x16 d0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d1 = d0;
-            if (u0 < f1) d0 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0));
-            if (per_wave > 16 && u0 + 16 < f1) d1 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0 + 16));
-            __syncthreads();                               // rows landed (first build) / the previous X has been multiplied
-            // ---- X: lane = row; 16 features -> 16 bytes -> one 16-byte LDS store
-            auto build16 = [&](const i32x16 &d, bool valid, int at) {
-                uint32_t pk[4] = {0u, 0u, 0u, 0u};
-                if (valid) {                               // (f1 is a multiple of 16: a group is in or out)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const uint32_t desc = (uint32_t)d[i];
-                        const uint32_t word = *reinterpret_cast<const uint32_t *>(my_row + (desc & 0xffffu));
-                        uint32_t b = (word >> (desc >> 16)) & 1u;
-                        if (!uniform_win) b &= own_mask >> (((desc & 0xffffu) >> 6) - sA);
-                        pk[i >> 2] |= b << (8 * (i & 3));
-                    }
-                }
-                *reinterpret_cast<uint4 *>(s_x + lane * XS + at) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-            };
-            build16(d0, u0 < f1, wave * per_wave);
-            if (per_wave > 16) build16(d1, u0 + 16 < f1, wave * per_wave + 16);
-            __syncthreads();                               // X complete
-            // ---- C += X * digits for this wave's 16 rows, every column block
-            if (mine) {
-                const int nkb = min((int)((f1 - x0 + 63) >> 6), XK >> 6);
-                v4i afrag[2];
-#pragma unroll
-                for (int kb = 0; kb < 2; ++kb)
-                    if (kb < nkb)
-                        afrag[kb] = *reinterpret_cast<const v4i *>(s_x + (16 * wave + (lane & 15)) * XS + 64 * kb + 16 * (lane >> 4));
-                const int8_t *bcol = dig + (size_t)(lane & 15) * U + (x0 - pf_first) + 16 * (lane >> 4);
-#pragma unroll
-                for (int cb = 0; cb < MW_MAX_CB; ++cb) {
-                    if (cb < ncb) {
-#pragma unroll
-                        for (int kb = 0; kb < 2; ++kb)
-                            if (kb < nkb) {
-                                const v4i bfrag = *reinterpret_cast<const v4i *>(bcol + (size_t)(16 * cb) * U + 64 * kb);
-                                acc[cb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(afrag[kb], bfrag, acc[cb], 0, 0, 0);
-                            }
-                    }
-                }
-            }
-        }
-    }
-    if (!mine) return;
-
-    // ---- this wave's rows, lane = (row r, group g): group g scores the children g, g + 4, ... of the node
+    // ---- the children this lane scores at the end: row r of this wave's 16, group g -> children g, g + 4, g + 8, g + 12
     const int r = lane & 15, g = lane >> 4;
     const int my_slot = 16 * wave + r;
     const int myseq = __shfl(seq, my_slot);
     const int r_lo = __shfl(own_lo, my_slot), r_hi = __shfl(own_hi, my_slot);
-    // the transposition scratch overlays this wave's own 16 rows of X (only this wave has read them, and its MFMAs
-    // are done with them) -- or, when X is the narrow one (which it is only under full-width staged rows), this
-    // wave's 16 staged rows: every wave passed the last "X complete" barrier, nobody reads rows or writes X any more
-    int *const scr = XK == 128 ? reinterpret_cast<int *>(s_x + (size_t)16 * wave * XS)
-                               : reinterpret_cast<int *>(s_rows + (size_t)16 * wave * stride);
-    double best_z = 0.0, best_raw = 0.0;
+    // (what R0 scores outside the row's window) + intercept for this lane's children of a round (g and g + 4 of the
+    // round's 8).  Branch-free -- children past the last one re-read the last one's constants and are never scored --
+    // so that the six loads are issued back to back and waited for once.
+    auto child_consts = [&](int rd, double (&kc)[2]) {
+        double gp[2], gs[2], ic[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c = c0 + min(8 * rd + 4 * h + g, k - 1);
+            const size_t base = (size_t)c * (a.NC + 1);
+            gp[h] = a.gappre[base + r_lo];
+            gs[h] = a.gapsuf[base + r_hi];
+            ic[h] = a.intercept[c];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) kc[h] = (gp[h] + gs[h]) + ic[h];
+    };
+    double kc0[2];
+    child_consts(0, kc0);
+
+    const int ncb = (k + 1) >> 1;                              // column blocks of 16 (two children each)
+    int *const ctile = reinterpret_cast<int *>(s_mem);
+    double best_raw = 0.0;
     int best_c = -1;
+    // A round = 8 children = column blocks 4 rd .. 4 rd + 3, one per wave.  Nodes with more than 8 children take a
+    // second round that stages and builds X again (the C tile of the first round has overwritten them).
+    for (int rd = 0; 8 * rd < k; ++rd) {
+        const int cb = wave + rd * NW;                         // this wave's column block of the round
+        double kc[2] = {kc0[0], kc0[1]};
+        if (rd) child_consts(1, kc);
+        v4i acc[4];
 #pragma unroll
-    for (int rd = 0; rd < MW_MAX_CB / 2; ++rd) {           // a round = 2 column blocks = 4 children
-        if (4 * rd < k) {
-            // C/D layout of the 16x16 tile: column = lane & 15, rows 4 (lane >> 4) .. + 3 in the 4 registers
+        for (int rb = 0; rb < 4; ++rb) acc[rb] = v4i{0, 0, 0, 0};
+        for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
+            const int sB = min(wB, sA + WCAP_CHUNKS);
+            if (sA != wA || rd) __syncthreads();           // the previous slice's X / rows (or the C tile) have been read
+            {   // row words of the slice -> LDS (LDS-DMA; lanes over words, one row per wave and step)
+                const int w0 = sA * CHUNK_WORDS;
+                const int width = min(sB * CHUNK_WORDS, a.W) - w0;
+                if (lane < width) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+                    for (int rr = 0; rr < TILE / NW; ++rr) {
+                        const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+#if STAG_ABL != 7
+                        if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
+#endif
+                    }
+                }
+            }
+            uint32_t f0, f1;
+            const int8_t *dig_win;                         // column 0, first feature of the slice
+            if (hinted) {
+                f0 = (uint32_t)t2[3];
+                f1 = f0 + (uint32_t)t2[4];
+                dig_win = m.dig + (((uint64_t)(uint32_t)t2[1] << 32) | (uint32_t)t2[0]);
+            } else {
+                f0 = as_const(m.pf_off)[(size_t)node * a.NC + sA];
+                f1 = as_const(m.pf_off)[(size_t)node * a.NC + sB];
+                dig_win = dig_node + (f0 - pf_first);
+            }
+            // this lane's own chunks inside the slice (bit i: chunk sA + i)
+            const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
+                                      ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
+            const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * stride * 4 - sA * (CHUNK_WORDS * 4));
+            for (uint32_t x0 = f0; x0 < f1; x0 += XK) {
+                // descriptors of this wave's features (scalar) and its digit fragments: in flight across the barrier
+                const uint32_t u0 = x0 + wave * per_wave;
+                i32x16 d0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d1 = d0;
+                if (u0 < f1) d0 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0));
+                if (per_wave > 16 && u0 + 16 < f1) d1 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0 + 16));
+                const int nkb = min((int)((f1 - x0 + 63) >> 6), XK >> 6);
+                // branch-free (a wave without a column block, or a second 64-feature block that does not exist, re-reads
+                // a fragment that exists; those MFMAs are skipped below): loads in a branch would be waited for at its end
+                v4i bf[2];
+                {
+                    const int8_t *bp = dig_win + (size_t)(16 * min(cb, ncb - 1) + (lane & 15)) * U + (x0 - f0) + 16 * (lane >> 4);
+                    bf[0] = *reinterpret_cast<const v4i *>(bp);
+                    bf[1] = *reinterpret_cast<const v4i *>(bp + (nkb > 1 ? 64 : 0));
+                }
+                STAG_STAMP(1);   // everything issued
+                __syncthreads();                           // rows landed (first build) / the previous X has been multiplied
+                STAG_STAMP(2);   // rows, descriptors, fragments arrived
+                // ---- X: lane = row; 16 features -> 16 bytes -> one 16-byte LDS store
+                auto build16 = [&](const i32x16 &d, bool valid, int at) {
+                    uint32_t pk[4] = {0u, 0u, 0u, 0u};
+                    if (valid) {                           // (f1 is a multiple of 16: a group is in or out)
+#pragma unroll
+                        for (int h8 = 0; h8 < 16; h8 += 8) {   // eight LDS reads in flight together
+                            uint32_t word[8];
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+                                word[i] = *reinterpret_cast<const uint32_t *>(my_row + ((uint32_t)d[h8 + i] & 0xffffu));
+                            if (uniform_win) {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i)
+                                    pk[(h8 + i) >> 2] |= ((word[i] >> ((uint32_t)d[h8 + i] >> 16)) & 1u) << (8 * (i & 3));
+                            } else {
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) {
+                                    const uint32_t desc = (uint32_t)d[h8 + i];
+                                    const uint32_t bit = (word[i] >> (desc >> 16)) & (own_mask >> (((desc & 0xffffu) >> 6) - sA)) & 1u;
+                                    pk[(h8 + i) >> 2] |= bit << (8 * (i & 3));
+                                }
+                            }
+                        }
+                    }
+                    *reinterpret_cast<uint4 *>(s_x + lane * XS + at) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                };
+#if STAG_ABL != 8
+                build16(d0, u0 < f1, wave * per_wave);
+                if (per_wave > 16) build16(d1, u0 + 16 < f1, wave * per_wave + 16);
+#endif
+                STAG_STAMP(3);   // X built
+                __syncthreads();                           // X complete
+                STAG_STAMP(4);
+                // ---- C += X * digits: all 64 rows, this wave's column block
+                if (cb < ncb) {
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+                        if (kb < nkb) {
+#pragma unroll
+                            for (int rb = 0; rb < 4; ++rb) {
+                                const v4i af = *reinterpret_cast<const v4i *>(s_x + (16 * rb + (lane & 15)) * XS + 64 * kb + 16 * (lane >> 4));
+                                acc[rb] = __builtin_amdgcn_mfma_i32_16x16x64_i8(af, bf[kb], acc[rb], 0, 0, 0);
+                            }
+                        }
+                }
+            }
+        }
+        STAG_STAMP(5);   // MFMAs issued
+        // ---- scores of the round's 8 children through the C tile: [64 rows][4 column blocks]
+        __syncthreads();                                   // X has been read by everyone
+        if (cb < ncb) {
+            // C/D layout of a 16x16 tile: column = lane & 15, rows 4 (lane >> 4) .. + 3 in the 4 registers
+#pragma unroll
+            for (int rb = 0; rb < 4; ++rb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    scr[(4 * (lane >> 4) + q) * MW_SCR_STRIDE + 16 * h + (lane & 15)] = acc[2 * rd + h][q];
-            const int j = 4 * rd + g;                      // this lane's child in the round
-            const int *cr = scr + r * MW_SCR_STRIDE + 8 * g;
-            double v = (double)cr[5];
+                    ctile[(16 * rb + 4 * (lane >> 4) + q) * MW_C_STRIDE + 16 * wave + (lane & 15)] = acc[rb][q];
+        }
+        __syncthreads();
 #pragma unroll
-            for (int sl = 4; sl >= 0; --sl) v = v * 256.0 + (double)cr[sl];
+        for (int h = 0; h < 2; ++h) {                      // this lane's children 8 rd + g and 8 rd + 4 + g
+            const int j = 8 * rd + 4 * h + g;
             if (j < k) {
-                const int c = c0 + j;
-                const size_t base = (size_t)c * (a.NC + 1);
-                const double z = ((a.gappre[base + r_lo] + a.gapsuf[base + r_hi]) + v * qs) + a.intercept[c];
-                const double zc = clamp_z(z);
-                if (best_c < 0 || zc > best_z) { best_z = zc; best_raw = z; best_c = c; }   // strict '>' in stored order
+                const int *cr = ctile + my_slot * MW_C_STRIDE + 8 * (4 * h + g);
+                double v = (double)cr[5];
+#pragma unroll
+                for (int sl = 4; sl >= 0; --sl) v = v * 256.0 + (double)cr[sl];
+                const double z = kc[h] + v * qs;
+                if (best_c < 0 || beats(z, best_raw)) { best_raw = z; best_c = c0 + j; }   // strict '>' in stored order
             }
         }
     }
-    // ---- first maximum in stored order over the four lane groups of a row: largest z, then smallest child
+    STAG_STAMP(6);   // tile turned around, scores
+    // ---- first maximum in stored order over the four lane groups of a row: largest probability, then smallest child
 #pragma unroll
     for (int step = 16; step <= 32; step <<= 1) {
-        const double oz = __shfl_xor(best_z, step), oraw = __shfl_xor(best_raw, step);
+        const double oraw = __shfl_xor(best_raw, step);
         const int oc = __shfl_xor(best_c, step);
-        if (oc >= 0 && (best_c < 0 || oz > best_z || (oz == best_z && oc < best_c))) { best_z = oz; best_raw = oraw; best_c = oc; }
+        if (oc >= 0 && (best_c < 0 || beats(oraw, best_raw) || (oc < best_c && !beats(best_raw, oraw)))) { best_raw = oraw; best_c = oc; }
     }
     if (g == 0 && myseq >= 0) {
         LevelRec rec;
@@ -1321,6 +1438,14 @@ __global__ __launch_bounds__(NW * 64, 7) void k_walk_mfma(WalkArgs a, MfmaArgs m
         rec.prob = sigmoid(best_raw);
         a.lvl[myseq] = rec;
     }
+    STAG_STAMP(7);   // reduction, sigmoid, store
+#if STAG_ABL == 10
+    if (threadIdx.x == 0) {      // one slot of 16 counters per 4096 workgroups: no hot address
+        unsigned long long *slot = a.dbg + 16 * (blockIdx.x & 4095);
+        for (int i = 0; i < 8; ++i) atomicAdd(slot + i, phase_[i]);
+        atomicAdd(slot + 15, 1ull);
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------

@@ -202,7 +202,7 @@ def test_matrix_core_walk_equals_gather_walk_on_c2(c2, monkeypatch):
     monkeypatch.setenv("STAG_WALK", "gather")
     with Database(t) as db:
         ref = run(db, text, offs, idx)
-    monkeypatch.setenv("STAG_WALK", "auto")
+    monkeypatch.setenv("STAG_WALK", "mfma")
     with Database(t) as db:
         got = run(db, text, offs, idx)
         perm = np.random.default_rng(3).permutation(len(idx))

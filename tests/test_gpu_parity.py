@@ -16,11 +16,12 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-@pytest.fixture(autouse=True, params=["auto", "gather"])
+@pytest.fixture(autouse=True, params=["mfma", "gather"])
 def walk_kernel(request, monkeypatch):
-    """Every test of this file runs twice: with the walk the library picks per node (the matrix-core kernel
-    k_walk_mfma wherever a node has its tables) and with STAG_WALK=gather, which sends every node through the
-    gather kernel k_walk_level (read by stag_db_create)."""
+    """Every test of this file runs twice: with STAG_WALK=mfma, which sends every node that can be through the
+    matrix-core kernel k_walk_mfma (nodes with more than 16 children or non-finite coefficients still take the
+    gather kernel), and with STAG_WALK=gather, which sends every node through k_walk_level.  (Left alone,
+    stag_db_create picks per node by the density of the children's rows.)"""
     monkeypatch.setenv("STAG_WALK", request.param)
     return request.param
 
