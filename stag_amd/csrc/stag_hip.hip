@@ -240,7 +240,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
     int G = 64;
     int64_t best_slots = -1;
     for (int g : {64, 32, 16}) {
-        const int64_t slots = ((avg + 16 * g - 1) / (16 * g)) * g;
+        const int64_t slots = ((avg + 32 * g - 1) / (32 * g)) * g;      // a lane takes 32 bytes per step
         const size_t need = (size_t)4 * (64 / g) * W * sizeof(uint32_t);
         if (need > 160 * 1024) continue;
         if (best_slots < 0 || slots < best_slots) { best_slots = slots; G = g; }

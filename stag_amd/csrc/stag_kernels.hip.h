@@ -181,8 +181,8 @@ __device__ __forceinline__ void emit_groups(uint32_t *row, int W, int col, uint6
 }
 
 // G = lanes per record (16, 32 or 64): a wave encodes 64/G records side by side, each lane
-// taking 16 bytes of its record per step.  The host picks G so that a record's length wastes few
-// lane slots (a 1,501-byte record is 2 steps of 64 lanes = 2,048 slots, or 3 steps of 32 = 1,536).
+// taking 32 bytes (two 16-byte vectors) of its record per step.  The host picks G so that a record's length
+// wastes few lane slots (a 1,501-byte record is 3 steps of 16 lanes = 1,536 bytes' worth).
 // FULL: every word of the row is stored (stag_encode_a2m*, -S).  !FULL (the classify paths): only the 16-word
 // chunks that hold the row's window are stored -- everything else equals R0, which the walk never reads from
 // memory (k_walk_level scores a row outside its own window from the gap chains) -- so an amplicon read costs
@@ -221,10 +221,12 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     // shorter than 2 GB); only the load address is 64-bit.
     const int len = (int)(end - begin);
     const int lead = (int)(begin - base);        // bytes of the first vector that precede the record
-    // text_bytes is a multiple of 16 (checked by the host side), so a 16-byte vector is either
-    // entirely inside the buffer or entirely outside the record
-    // also fetches the mask of the vector's bytes that belong to the record: [lo_cut, hi_cut) of 16
-    // (all ones except in a record's first and last vector)
+    // A lane takes VPL = 2 vectors of 16 bytes per step: half as many steps, lanes and (per record) prologue and
+    // epilogue instructions as with one.  text_bytes is a multiple of 16 (checked by the host side), so a 16-byte
+    // vector is either entirely inside the buffer or entirely outside the record.  A load also fetches the mask of
+    // the vector's bytes that belong to the record: [lo_cut, hi_cut) of 16 (all ones except in a record's first and
+    // last vector).
+    constexpr int VPL = 2, STEP = 16 * VPL * G;  // bytes of a record per step
     auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
         if (rel < len && p >= 0 && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
@@ -235,31 +237,11 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         if (lo_cut > 0 || hi_cut < 16) q = *reinterpret_cast<const uint4 *>(KEEP_LUT.m[lo_cut * 17 + hi_cut]);
         k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
     };
-    uint32_t nxt[4], nxt_keep[4];
-    int64_t p = base + (int64_t)gl * 16;         // this lane's vector of the current step
-    load16(p, gl * 16 - lead, nxt, nxt_keep);
-    for (int rel0 = -lead; __ballot(rel0 < len) != 0ull; rel0 += 16 * G, p += 16 * G) {
-        const int rel = rel0 + gl * 16;          // of the lane's vector; negative only in the first step
-        uint32_t wv[4] = {nxt[0], nxt[1], nxt[2], nxt[3]};
-        const uint32_t keep[4] = {nxt_keep[0], nxt_keep[1], nxt_keep[2], nxt_keep[3]};
-        load16(p + 16 * G, rel + 16 * G, nxt, nxt_keep);   // the next vector is in flight while this one is encoded
-        // Aligned amplicon reads are mostly runs of '-': when every valid byte of every lane is a
-        // gap, the step's output is a prefix of a constant bit pattern (bit 0 of each column).
-        const bool all_gap = ((((wv[0] ^ 0x2d2d2d2du) & keep[0]) | ((wv[1] ^ 0x2d2d2d2du) & keep[1]) |
-                               ((wv[2] ^ 0x2d2d2d2du) & keep[2]) | ((wv[3] ^ 0x2d2d2d2du) & keep[3])) == 0u);
-        if (__ballot(!all_gap) == 0ull) {
-            // the row already says "gap" everywhere: only the column count moves on, by the bytes
-            // of this step that belong to the record
-            running += max(0, min(len, rel0 + 16 * G) - max(0, rel0));
-            continue;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wv[j] = (wv[j] & keep[j]) | (0x0a0a0a0au & ~keep[j]);   // invalid -> '\n' = skipped
-        // Branch-free SWAR over the 4 dwords: classify 4 bytes at a time.
-        uint32_t code[4], skip80[4];
+    // one vector: its bytes' (one-hot group ^ gap group) in code, the skipped bytes in skip80, A/C/G/T/U counted
+    auto classify16 = [&](const uint32_t (&wv)[4], const uint32_t (&keep)[4], uint32_t (&code)[4], uint32_t (&skip80)[4]) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t x = wv[j];
+            const uint32_t x = (wv[j] & keep[j]) | (0x0a0a0a0au & ~keep[j]);   // not the record's -> '\n' = skipped
             const uint32_t t = x & 0x7f7f7f7fu;
             // skipped: 'a'..'z' (HMM insert states, align.py:47) and 0x0a..0x0d (line breaks)
             const uint32_t ge61 = t + 0x1f1f1f1fu, ge7b = t + 0x05050505u;
@@ -276,48 +258,104 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             code[j] = (oneh ^ 0x01010101u) & eqm;   // group ^ gap group: zero for anything that is not A/C/G/T/U
             aligned += __popc(eq80);
         }
-        uint64_t lo;
-        uint32_t hi;
-        int before, total;   // groups emitted by the lanes before this one in the record, and by the whole record
-        if (__ballot((skip80[0] | skip80[1] | skip80[2] | skip80[3]) != 0u) == 0ull) {
-            // no insert / line break anywhere in this step: byte j is column j, positions are static
-            uint32_t pk[4];
+    };
+    // 16 columns' groups -> 80 bits (byte j is column j)
+    auto pack_static = [&](const uint32_t (&code)[4], uint64_t &lo, uint32_t &hi) {
+        uint32_t pk[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                pk[j] = (code[j] & 0x1fu) | ((code[j] >> 3) & 0x3e0u) | ((code[j] >> 6) & 0x7c00u) | ((code[j] >> 9) & 0xf8000u);
-            lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << 20) | ((uint64_t)pk[2] << 40) | ((uint64_t)pk[3] << 60);
-            hi = pk[3] >> 4;
-            before = 16 * gl;
-            total = 16 * G;
-        } else {
-            // pack the kept bytes' 5-bit groups densely (a skipped byte contributes no group)
-            uint32_t pk[4];
-            int cnt[4];
+        for (int j = 0; j < 4; ++j)
+            pk[j] = (code[j] & 0x1fu) | ((code[j] >> 3) & 0x3e0u) | ((code[j] >> 6) & 0x7c00u) | ((code[j] >> 9) & 0xf8000u);
+        lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << 20) | ((uint64_t)pk[2] << 40) | ((uint64_t)pk[3] << 60);
+        hi = pk[3] >> 4;
+    };
+    // the kept bytes' groups packed densely (a skipped byte contributes no group); returns how many
+    auto pack_dense = [&](const uint32_t (&code)[4], const uint32_t (&skip80)[4], uint64_t &lo, uint32_t &hi) {
+        uint32_t pk[4];
+        int cnt[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint32_t c = code[j] & ~((skip80[j] >> 7) * 0xffu);
-                const uint32_t k0 = ((skip80[j] >> 7) & 1u) ^ 1u, k1 = ((skip80[j] >> 15) & 1u) ^ 1u;
-                const uint32_t k2 = ((skip80[j] >> 23) & 1u) ^ 1u, k3 = (skip80[j] >> 31) ^ 1u;
-                const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
-                pk[j] = (c & 0x1fu) | (((c >> 8) & 0x1fu) << s1) | (((c >> 16) & 0x1fu) << s2) | ((c >> 24) << s3);
-                cnt[j] = (int)(k0 + k1 + k2 + k3);
-            }
-            const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
-            lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) | ((uint64_t)pk[3] << sh3);
-            hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
-            const int k = cnt[0] + cnt[1] + cnt[2] + cnt[3];
-            // inclusive prefix sum inside each record's lane group (DPP: rows of 16, then row carries)
-            int v = k;
-            v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
-            v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
-            v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
-            v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
-            if (G >= 32) v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
-            if (G >= 64) v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-            before = v - k;
-            total = __shfl(v, (lane & ~(G - 1)) + G - 1);   // the inclusive sum of the group's last lane
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t c = code[j] & ~((skip80[j] >> 7) * 0xffu);
+            const uint32_t k0 = ((skip80[j] >> 7) & 1u) ^ 1u, k1 = ((skip80[j] >> 15) & 1u) ^ 1u;
+            const uint32_t k2 = ((skip80[j] >> 23) & 1u) ^ 1u, k3 = (skip80[j] >> 31) ^ 1u;
+            const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
+            pk[j] = (c & 0x1fu) | (((c >> 8) & 0x1fu) << s1) | (((c >> 16) & 0x1fu) << s2) | ((c >> 24) << s3);
+            cnt[j] = (int)(k0 + k1 + k2 + k3);
         }
-        emit_groups(row, W, running + before, lo, hi, w_lo, w_hi);
+        const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
+        lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) | ((uint64_t)pk[3] << sh3);
+        hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
+        return cnt[0] + cnt[1] + cnt[2] + cnt[3];
+    };
+    uint32_t nxt[VPL][4], nxt_keep[VPL][4];
+    int64_t p = base + (int64_t)gl * (16 * VPL);     // this lane's first vector of the current step
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) load16(p + 16 * v, gl * (16 * VPL) + 16 * v - lead, nxt[v], nxt_keep[v]);
+    for (int rel0 = -lead; __ballot(rel0 < len) != 0ull; rel0 += STEP, p += STEP) {
+        const int rel = rel0 + gl * (16 * VPL);  // of the lane's first vector; negative only in the first step
+        uint32_t wv[VPL][4], keep[VPL][4];
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { wv[v][j] = nxt[v][j]; keep[v][j] = nxt_keep[v][j]; }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)            // the next vectors are in flight while these are encoded
+            load16(p + STEP + 16 * v, rel + STEP + 16 * v, nxt[v], nxt_keep[v]);
+        // Aligned amplicon reads are mostly runs of '-': when every valid byte of every lane is a
+        // gap, the step's output is a prefix of a constant bit pattern (bit 0 of each column).
+        uint32_t not_gap = 0u;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) not_gap |= (wv[v][j] ^ 0x2d2d2d2du) & keep[v][j];
+        if (__ballot(not_gap != 0u) == 0ull) {
+            // the row already says "gap" everywhere: only the column count moves on, by the bytes
+            // of this step that belong to the record
+            running += max(0, min(len, rel0 + STEP) - max(0, rel0));
+            continue;
+        }
+        uint32_t code[VPL][4], skip80[VPL][4];
+        uint32_t any_skip = 0u;
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) {
+            classify16(wv[v], keep[v], code[v], skip80[v]);
+            any_skip |= skip80[v][0] | skip80[v][1] | skip80[v][2] | skip80[v][3];
+        }
+        uint64_t lo[VPL];
+        uint32_t hi[VPL];
+        int at[VPL], total;   // where each vector's groups go (in columns of the record), and the step's columns
+        if (__ballot(any_skip != 0u) == 0ull) {
+            // no insert / line break anywhere in this step: byte j is column j, positions are static
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                pack_static(code[v], lo[v], hi[v]);
+                at[v] = running + 16 * VPL * gl + 16 * v;
+            }
+            total = STEP;
+        } else {
+            int cnt[VPL], k = 0;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                cnt[v] = pack_dense(code[v], skip80[v], lo[v], hi[v]);
+                k += cnt[v];
+            }
+            // inclusive prefix sum inside each record's lane group (DPP: rows of 16, then row carries)
+            int s = k;
+            s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xf, 0xf, false);  // row_shr:1
+            s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xf, 0xf, false);  // row_shr:2
+            s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xf, 0xf, false);  // row_shr:4
+            s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xf, 0xf, false);  // row_shr:8
+            if (G >= 32) s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+            if (G >= 64) s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+            int before = running + s - k;
+#pragma unroll
+            for (int v = 0; v < VPL; ++v) {
+                at[v] = before;
+                before += cnt[v];
+            }
+            total = __shfl(s, (lane & ~(G - 1)) + G - 1);   // the inclusive sum of the group's last lane
+        }
+#pragma unroll
+        for (int v = 0; v < VPL; ++v) emit_groups(row, W, at[v], lo[v], hi[v], w_lo, w_hi);
         running += total;
     }
     // totals over the record's lanes: valid in the group's last lane, which writes the record's scalars
