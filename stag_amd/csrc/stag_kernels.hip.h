@@ -61,8 +61,8 @@ struct Task {       // 128 bytes; a walk kernel reads the first 32 and its own 3
     // task's windows differs, the walk does the lookups itself.
     int32_t hA, hB;
     int32_t mfma, pad1;                // mfma: the node has matrix-core tables (k_walk_mfma's task)
-    // k_walk_level: where the coefficients of the first NW siblings (one per wave) sit for the hint window, in entries
-    uint32_t e_lo[4], e_hi[4];
+    uint32_t unused[8];                // (k_walk_level looks its coefficient ranges up itself: resolving them here
+                                       // made the grouping slower and the walk no faster)
     // k_walk_mfma: the node's digit matrix and the hint window's union features
     uint64_t dig_at;                   // byte offset in dig of column 0's digit of the window's first feature
     uint32_t U;                        // bytes per column
@@ -758,7 +758,7 @@ __device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint
     tk.mfma = mfma ? 1 : 0;
     tk.dig_at = 0; tk.U = 0; tk.f0 = 0; tk.nf = 0; tk.qscale = 0.0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { tk.e_lo[j] = 0; tk.e_hi[j] = 0; }
+    for (int j = 0; j < 8; ++j) tk.unused[j] = 0;
     if (mfma) {
         const uint32_t *po = h.pf_off + (size_t)nd * h.NC;
         const uint32_t first = po[0], f0 = po[hA], f1 = po[hB];
@@ -767,14 +767,6 @@ __device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint
         tk.nf = f1 - f0;
         tk.dig_at = h.dig_base[nd] + (f0 - first);
         tk.qscale = h.qscale[nd];
-    } else if (hB > hA) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (j < k) {
-                const uint32_t *bo = h.blk_off + (size_t)(c0 + j) * h.NC;
-                tk.e_lo[j] = bo[hA] * BLOCK_ENTRIES;
-                tk.e_hi[j] = bo[hB] * BLOCK_ENTRIES;
-            }
     }
     return tk;
 }
@@ -932,7 +924,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int n_tasks = *as_const(a.n_tasks);
-    const i32x16 tk = as_const(reinterpret_cast<const i32x16 *>(a.tasks))[2 * blockIdx.x];
+    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x];
     // the task's slots of order[] sit at a fixed place: fetched together with the task record
     // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
     SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];
@@ -1088,14 +1080,9 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             z = gap_consts(c0 + wave);
 #endif
             if (windowed) {
-                if (tk[4] == wA && tk[5] == wB) {      // the hint fits: no lookup
-                    e_lo = (uint32_t)(wave == 0 ? tk[8] : wave == 1 ? tk[9] : wave == 2 ? tk[10] : tk[11]);
-                    e_hi = (uint32_t)(wave == 0 ? tk[12] : wave == 1 ? tk[13] : wave == 2 ? tk[14] : tk[15]);
-                } else {
-                    const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave) * a.NC;
-                    e_lo = bo[wA] * BLOCK_ENTRIES;
-                    e_hi = bo[wB] * BLOCK_ENTRIES;
-                }
+                const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave) * a.NC;
+                e_lo = bo[wA] * BLOCK_ENTRIES;
+                e_hi = bo[wB] * BLOCK_ENTRIES;
             }
         }
         if (windowed) {
