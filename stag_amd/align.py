@@ -112,17 +112,18 @@ def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
     _finish_aligner(align_proc, parse_proc)
 
 
-def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose, size=None):
+def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose, size=None, ring_slots=2):
     """Batches (ids, text uint8, offs int64, gene) of aligned records, parsed in C
     (stag_amd.ingest.fasta_batches: no Python string per record).  gene is None for nucleotide
     databases (text/offs is the A2M alignment, for Database.classify_a2m_text); for protein
     databases text/offs is the protein alignment and gene = (gene text, gene offs) of the same
     records (align.py:148-158), for Database.classify_protein_a2m_text, which back-translates
-    on the GPU."""
+    on the GPU.  ring_slots: how many batches of a nucleotide database stay valid at a time (their text sits in a
+    ring of page-locked buffers; the caller keeps ring_slots - 2 batches in flight)."""
     size = size or BATCH_RECORDS
     align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
     if not protein_file:
-        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size, pinned=True):
+        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size, pinned=True, ring_slots=ring_slots):
             yield ids, text, offs, None
         _finish_aligner(align_proc, parse_proc)
         return

@@ -6,6 +6,7 @@ classify_seq) becomes batches through the HIP kernels (stag_amd.engine.Database)
 parsing and text formatting stay on the host.  ``threads`` is accepted and, as in the
 reference (classify.py:94), only reaches ``cmalign --cpu``.
 """
+import collections
 import contextlib
 import os
 import shutil
@@ -45,24 +46,40 @@ def alignment_reader(aligned_sequences):
             yield parse_onehot_line(ali_line)
 
 
-def _classify_prealigned(db, aligned_sequences, tagged, state):
+def _in_flight(pool):
+    """Batches handed to the devices before the oldest one's result is taken: one per device and one more
+    being prepared for each, or none ahead with a single device (the reference's own order of events)."""
+    return 2 * len(pool.dbs) if len(pool.dbs) > 1 else 1
+
+
+def _classify_prealigned(pool, aligned_sequences, tagged, state):
     """-s path: rows arrive already one-hot encoded (any bit pattern).  The file is parsed in C
     (stag_amd.ingest.onehot_batches) straight into packed rows; lines it does not take literally
-    go through parse_onehot_line.  Under torchrun the batches of the stream are dealt round-robin
-    to the ranks (parallel.owner_of_batch)."""
+    go through parse_onehot_line.  One parser; the batches go to the pool's devices in input order.
+    Under torchrun the batches of the stream are dealt round-robin to the ranks (parallel.owner_of_batch)."""
     world, rank = parallel.world_rank()
+    db = pool.first
     L = db.n_features
     batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
                                     slow_line=parse_onehot_line)
-    for b, (ids, bits, n_fields) in enumerate(batches):
+    pending = collections.deque()
+
+    def finish_oldest():
+        b, ids, fut = pending.popleft()
         state["batch"] = b
+        tagged.append((b, db.result_rows(fut.result(), ids, long_out=True)))
+
+    for b, (ids, bits, n_fields) in enumerate(batches):
         if not state["alignment_length"]:
             state["alignment_length"] = int(n_fields[0])
         if parallel.owner_of_batch(b, world) != rank:
             continue
         status = np.where(n_fields == L, _lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH).astype(np.int32)
-        res = db.classify_bits(bits, status)
-        tagged.append((b, db.result_rows(res, ids, long_out=True)))
+        pending.append((b, ids, pool.submit(lambda d, bits=bits, status=status: d.classify_bits(bits, status))))
+        while len(pending) >= _in_flight(pool):
+            finish_oldest()
+    while pending:
+        finish_oldest()
 
 
 def _report_backtranslation_failure(status, ids, text, offs, gene):
@@ -100,8 +117,11 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
             with open_stagdb(database) as db_in:
                 use_proteins = bool(db_in.read("align_protein")[0])
             table_cache.store(database, tables, hmm_file_path, use_cmalign, use_proteins, db_tool_version)
-    db = Database(tables, device=parallel.local_device() if device is None else device)
     world, rank = parallel.world_rank()
+    # one process can drive several GPUs (STAG_DEVICES): tables replicated, batches dealt in input order
+    devices = [device] if device is not None else (parallel.devices_from_env() if world == 1 else [parallel.local_device()])
+    pool = parallel.DevicePool(lambda d: Database(tables, device=d), devices)
+    db = pool.first
     time_after_loading = time.time()
     if verbose > 2:
         sys.stderr.write("Load database: " + str("{0:.2f}".format(time_after_loading - t0)) + " sec\n")
@@ -117,52 +137,66 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                 res = db.classify_concat(concat_source["gene_len"], concat_source["gene_rows"], concat_source["src_row"])
                 tagged.append((0, db.result_rows(res, concat_source["ids"], long_out=True)))
         elif aligned_sequences:
-            _classify_prealigned(db, aligned_sequences, tagged, state)
+            _classify_prealigned(pool, aligned_sequences, tagged, state)
         else:
             batches = align.aligned_batches(fasta_input, protein_fasta_input, hmm_file_path, use_cmalign,
-                                            threads, verbose)
+                                            threads, verbose, ring_slots=_in_flight(pool) + 2)
             alignment_out = open(save_ali_to_file, "wb") if save_ali_to_file and rank == 0 else contextlib.nullcontext()
+            want_bits = bool(save_ali_to_file) and rank == 0
+            pending = collections.deque()
+
+            def run(d, text, offs, gene):
+                if gene is None:
+                    return d.classify_a2m_text(text, offs, min_perc_state=min_perc_state, want_bits=want_bits)
+                # protein database: back-translation happens on the GPU (align.py:63-94)
+                return d.classify_protein_a2m_text(text, offs, gene[0], gene[1], min_perc_state=min_perc_state,
+                                                   want_bits=want_bits)
+
+            def finish_oldest():
+                """What the reference does after classifying the sequences of a batch, in input order."""
+                nonlocal n_pass, n_not_pass
+                b, mine, ids, text, offs, gene, fut = pending.popleft()
+                state["batch"] = b
+                res = fut.result()
+                _report_backtranslation_failure(res.status, ids, text, offs, gene)
+                failed = np.flatnonzero((res.status != _lib.SEQ_OK) & (res.status != _lib.SEQ_FILTERED))
+                if failed.size:
+                    # the reference stops at the first failing sequence; by then it has written the -S
+                    # lines of the sequences before it (classify.py:158-162)
+                    before = np.flatnonzero(res.status[:failed[0]] == _lib.SEQ_OK)
+                    if want_bits and len(before):
+                        alignment_out.write(ingest.format_onehot([ids[i] for i in before], res.bits[before], db.n_features))
+                    raise_for_status(res.status, ids)
+                passed = np.flatnonzero(res.status == _lib.SEQ_OK)
+                n_pass += len(passed)
+                n_not_pass += len(ids) - len(passed)
+                if len(passed) and not state["alignment_length"]:
+                    state["alignment_length"] = 5 * int(res.n_char[passed[0]])
+                if mine:
+                    tagged.append((b, db.result_rows(res, ids, long_out=True)))
+                if want_bits and len(passed):      # classify.py:160-162
+                    alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed], db.n_features))
+                    if packed_rows_out is not None:
+                        packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
+
             with alignment_out:
                 for b, (ids, text, offs, gene) in enumerate(batches):
-                    state["batch"] = b
                     mine = parallel.owner_of_batch(b, world) == rank
-                    if not mine and not (save_ali_to_file and rank == 0) and state["alignment_length"]:
+                    if not mine and not want_bits and (state["alignment_length"] or pending):
                         continue
-                    want_bits = bool(save_ali_to_file) and rank == 0
-                    if gene is None:
-                        res = db.classify_a2m_text(text, offs, min_perc_state=min_perc_state, want_bits=want_bits)
-                    else:       # protein database: back-translation happens on the GPU (align.py:63-94)
-                        res = db.classify_protein_a2m_text(text, offs, gene[0], gene[1], min_perc_state=min_perc_state,
-                                                           want_bits=want_bits)
-                    _report_backtranslation_failure(res.status, ids, text, offs, gene)
-                    failed = np.flatnonzero((res.status != _lib.SEQ_OK) & (res.status != _lib.SEQ_FILTERED))
-                    if failed.size:
-                        # the reference stops at the first failing sequence; by then it has written the -S
-                        # lines of the sequences before it (classify.py:158-162)
-                        before = np.flatnonzero(res.status[:failed[0]] == _lib.SEQ_OK)
-                        if save_ali_to_file and rank == 0 and len(before):
-                            alignment_out.write(ingest.format_onehot([ids[i] for i in before], res.bits[before],
-                                                                     db.n_features))
-                        raise_for_status(res.status, ids)
-                    passed = np.flatnonzero(res.status == _lib.SEQ_OK)
-                    n_pass += len(passed)
-                    n_not_pass += len(ids) - len(passed)
-                    if len(passed) and not state["alignment_length"]:
-                        state["alignment_length"] = 5 * int(res.n_char[passed[0]])
-                    if mine:
-                        tagged.append((b, db.result_rows(res, ids, long_out=True)))
-                    if save_ali_to_file and rank == 0 and len(passed):      # classify.py:160-162
-                        alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed],
-                                                                 db.n_features))
-                        if packed_rows_out is not None:
-                            packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
+                    pending.append((b, mine, ids, text, offs, gene,
+                                    pool.submit(lambda d, t=text, o=offs, g=gene: run(d, t, o, g))))
+                    while len(pending) >= _in_flight(pool):
+                        finish_oldest()
+                while pending:
+                    finish_oldest()
             if verbose > 3 and world == 1:
                 print(f" Number of sequences that pass the filter: {n_pass}", file=sys.stderr)
                 print(f" Number of sequences that do not pass the filter: {n_not_pass}", file=sys.stderr)
     except Exception as e:       # re-raised on every rank by gather_in_order
         error = e
     finally:
-        db.close()
+        pool.close()
     if error is not None:
         os.remove(hmm_file_path)
     list_to_print = parallel.gather_in_order(tagged, error, state["batch"])

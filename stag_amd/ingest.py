@@ -79,16 +79,16 @@ def _fill(stream, buf, have):
 
 
 class _TextRing:
-    """Two page-locked text buffers (stag_host_alloc) used in turn: the batch handed to the caller sits in one
-    while the next is assembled in the other, so the GPU's copy engine reads batches by DMA (the pipeline of
+    """A few page-locked text buffers (stag_host_alloc) used in turn: the batches handed to the caller sit in
+    some while the next is assembled in another, so the GPU's copy engine reads batches by DMA (the pipeline of
     stag_classify_a2m overlaps its copies only from such memory).  Without a usable GPU library the buffers
     are ordinary arrays."""
 
-    def __init__(self):
-        self.bufs, self.turn, self.ok = [None, None], 0, True
+    def __init__(self, slots=2):
+        self.bufs, self.turn, self.ok = [None] * max(slots, 2), 0, True
 
     def take(self, nbytes):
-        self.turn ^= 1
+        self.turn = (self.turn + 1) % len(self.bufs)
         cur = self.bufs[self.turn]
         if cur is not None and len(cur[1]) >= nbytes:
             return cur[1][:nbytes]
@@ -106,17 +106,18 @@ class _TextRing:
         return arr[1][:nbytes]
 
 
-def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False, pinned=False):
+def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False, pinned=False,
+                  ring_slots=2):
     """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
     (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1); with
     text_mode, as read_fasta(open(path), is_binary=False): universal newlines, so a lone '\r' also
     ends a line (the gene file of align.py:150).  batch_records is a target, not a bound: records
     that had to be re-parsed the slow way are all added to the batch that was being filled.
-    pinned: the text arrays are views of two page-locked buffers used in turn (a batch stays valid until the
-    batch after the next one is produced)."""
+    pinned: the text arrays are views of ring_slots page-locked buffers used in turn (a batch stays valid until
+    ring_slots - 1 further batches have been produced)."""
     L = lib()
-    ring = _TextRing() if pinned else None
+    ring = _TextRing(ring_slots) if pinned else None
     buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
     scratch = np.empty(len(buf), dtype=np.uint8)
     have, at_start, ended = 0, True, False

@@ -43,9 +43,68 @@ def local_device():
     return int(os.environ.get("STAG_DEVICE", os.environ.get("LOCAL_RANK", "0")))
 
 
-def shard_bounds(n, world):
-    """Contiguous index ranges [i*n/world, (i+1)*n/world)."""
-    return [((i * n) // world, ((i + 1) * n) // world) for i in range(world)]
+def devices_from_env():
+    """GPUs one process drives (one host thread + one handle per device): STAG_DEVICES="0,1,2,3",
+    or "all".  Default: the single device of local_device()."""
+    spec = os.environ.get("STAG_DEVICES", "").strip()
+    if not spec:
+        return [local_device()]
+    if spec.lower() == "all":
+        from . import _lib
+        return list(range(max(_lib.device_count(), 1)))
+    return [int(tok) for tok in spec.split(",") if tok.strip() != ""]
+
+
+class DevicePool:
+    """One process, N GPUs: the tables are packed once and replicated (one Database per device), ONE aligner
+    and ONE parser feed batches -- contiguous ranges of the input, in input order -- to N worker threads, each
+    of which owns a device.  The calls into libstag_hip release the GIL, so the devices run side by side;
+    results come back per batch and are put in input order by the caller.  No collective: the path is
+    embarrassingly parallel (stag/classify.py:155-158 has no cross-sequence state).
+
+    submit(fn, *args) runs fn(database_of_some_device, *args) on the next free device and returns a future;
+    at most `depth` batches per device are in flight, so a fast parser cannot run ahead of the GPUs without bound."""
+
+    def __init__(self, make_database, devices, depth=2):
+        import queue
+        import threading
+        from concurrent.futures import Future
+        self._Future = Future
+        self.dbs = [make_database(d) for d in devices]
+        self._q = queue.Queue(maxsize=max(1, depth * len(self.dbs)))
+        self._threads = [threading.Thread(target=self._work, args=(db,), daemon=True) for db in self.dbs]
+        for t in self._threads:
+            t.start()
+
+    def _work(self, db):
+        while True:
+            item = self._q.get()
+            if item is None:
+                return
+            fut, fn, args = item
+            if not fut.set_running_or_notify_cancel():
+                continue
+            try:
+                fut.set_result(fn(db, *args))
+            except BaseException as e:      # delivered to the caller through the future
+                fut.set_exception(e)
+
+    @property
+    def first(self):
+        return self.dbs[0]
+
+    def submit(self, fn, *args):
+        fut = self._Future()
+        self._q.put((fut, fn, args))
+        return fut
+
+    def close(self):
+        for _ in self._threads:
+            self._q.put(None)
+        for t in self._threads:
+            t.join()
+        for db in self.dbs:
+            db.close()
 
 
 def owner_of_batch(batch_index, world):
@@ -77,11 +136,3 @@ def gather_in_order(tagged_rows, error=None, error_batch=0):
     return [r for _, rows in sorted(merged, key=lambda t: t[0]) for r in rows]
 
 
-def broadcast_object(obj, src=0):
-    world, _ = world_rank()
-    if world == 1:
-        return obj
-    import torch.distributed as dist
-    box = [obj]
-    dist.broadcast_object_list(box, src=src)
-    return box[0]

@@ -477,3 +477,58 @@ def test_command_line_classify_and_its_argument_errors(fake_gpu, monkeypatch, tm
         with pytest.raises(SystemExit) as e:
             main(argv)
         assert e.value.code == 1 and "[E::main] Error: " + message in capsys.readouterr().err
+
+
+@pytest.mark.skipif(databases._load_h5lib() is None, reason="libstag_h5.so not built")
+def test_one_process_driving_several_devices(engine, monkeypatch, tmp_path):
+    """STAG_DEVICES: one process, one aligner, one parser, a handle and a worker thread per device (here three
+    handles on device 0), batches dealt in input order.  Output, return value and the -S file equal the
+    single-device run's; so does the failure the reference would stop at, with the -S lines written before it."""
+    from stag_amd import align as sa
+    rng = np.random.default_rng(21)
+    sym = "-TGCA"
+    n = 83
+    strings = ["".join(sym[int(v)] for v in rng.integers(0, 5, size=29)) for _ in range(n)]
+    a2m = tmp_path / "replay.a2m"
+    a2m.write_text("".join(">r%d\n%s\n" % (i, s[:9] + "ac"[: i % 3] + s[9:]) for i, s in enumerate(strings)))
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s\n" % a2m)
+    (bindir / "esl-reformat").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat\n")
+    for t in ("hmmalign", "esl-reformat"):
+        os.chmod(bindir / t, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    monkeypatch.setattr(sa, "BATCH_RECORDS", 7)
+    monkeypatch.setattr(sc, "READER_BATCH", 7)
+    fasta = tmp_path / "reads.fasta"
+    fasta.write_text(">unused\nACGT\n")
+
+    def run(tag, devices):
+        if devices:
+            monkeypatch.setenv("STAG_DEVICES", devices)
+        else:
+            monkeypatch.delenv("STAG_DEVICES", raising=False)
+        out, saved = tmp_path / (tag + ".tsv"), tmp_path / (tag + ".ali")
+        ret = sc.classify(TINY, fasta_input=str(fasta), output=str(out), long_out=True, verbose=1, save_ali_to_file=str(saved))
+        return ret, out.read_text(), saved.read_text()
+
+    one = run("one", None)
+    three = run("three", "0,0,0")
+    assert three == one and len(one[0][1]) == n and one[0][0] == 145
+    # the pre-aligned path (-s) through the same pool
+    monkeypatch.setenv("STAG_DEVICES", "0,0")
+    ret = sc.classify(TINY, aligned_sequences=str(tmp_path / "one.ali"), output=str(tmp_path / "s.tsv"), long_out=True, verbose=1)
+    assert (tmp_path / "s.tsv").read_text() == one[1] and ret == one[0]
+    # a record of the wrong length in the middle: the reference fails there (ValueError: operands could not be
+    # broadcast), after writing the -S lines of everything before it
+    bad = strings[:40] + [strings[40][:-1]] + strings[41:]
+    a2m.write_text("".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(bad)))
+    for devices in (None, "0,0,0"):
+        if devices:
+            monkeypatch.setenv("STAG_DEVICES", devices)
+        else:
+            monkeypatch.delenv("STAG_DEVICES", raising=False)
+        saved = tmp_path / "partial.ali"
+        with pytest.raises(ValueError, match="broadcast"):
+            sc.classify(TINY, fasta_input=str(fasta), output=str(tmp_path / "never.tsv"), verbose=1, save_ali_to_file=str(saved))
+        assert len(saved.read_text().splitlines()) == 40 and not os.path.exists(tmp_path / "never.tsv")
