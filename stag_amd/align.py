@@ -127,23 +127,63 @@ def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
             yield ids, text, offs, None
         _finish_aligner(align_proc, parse_proc)
         return
+    # The two streams are paired record by record, as the reference's zip() does (align.py:148): the batchers cut
+    # them independently (batch_records is a target, not a bound), so whatever one side has beyond the other's
+    # batch waits for the other side's next batch.
+    import numpy as np
+
+    def take(side, stream):
+        """More records for `side` = [ids, text, offs] from its stream; False when the stream has ended."""
+        nxt = next(stream, None)
+        if nxt is None:
+            return False
+        ids, text, offs = nxt
+        if not side[0]:
+            side[:] = [list(ids), text, offs]
+        else:       # append behind the leftover
+            used = int(side[2][-1])
+            side[0] = side[0] + list(ids)
+            side[1] = np.concatenate([side[1][:used], text])
+            side[2] = np.concatenate([side[2], offs[1:] + used])
+        return True
+
+    def cut(side, m):
+        """The first m records of `side` as (ids, text, offs); `side` keeps the rest."""
+        ids, text, offs = side
+        head = (ids[:m], text, offs[:m + 1])
+        if m < len(ids):
+            lo = int(offs[m])
+            rest_text = text[lo:int(offs[-1])]
+            pad = np.zeros(-len(rest_text) % 16, dtype=np.uint8)
+            side[:] = [ids[m:], np.concatenate([rest_text, pad]), offs[m:] - lo]
+        else:
+            side[:] = [[], None, None]
+        return head
+
     with open(seq_file, "rb") as gene_fh:
         genes = ingest.fasta_batches(gene_fh, batch_records=size, text_mode=True)
-        for pids, ptext, poffs in ingest.fasta_batches(parse_proc.stdout, batch_records=size):
-            gids, gtext, goffs = next(genes, ([], None, None))
-            m = min(len(pids), len(gids))          # zip() stops with the shorter stream (align.py:148)
-            clash = next((j for j in range(m) if pids[j] != gids[j]), None)
+        prots = ingest.fasta_batches(parse_proc.stdout, batch_records=size)
+        P, G = [[], None, None], [[], None, None]
+        while True:
+            if not P[0] and not take(P, prots):
+                break
+            if not G[0] and not take(G, genes):
+                break                                  # zip() stops with the shorter stream
+            m = min(len(P[0]), len(G[0]))
+            clash = next((j for j in range(m) if P[0][j] != G[0][j]), None)
             if clash is not None:
                 # the reference gets this far only if the pairs before it went through (align.py:149-159):
                 # let them, then stop as it does
+                bad_p, bad_g = P[0][clash], G[0][clash]
                 if clash:
-                    yield pids[:clash], ptext, poffs[:clash + 1], (gtext, goffs[:clash + 1])
-                sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(pids[clash], gids[clash]))
+                    pids, ptext, poffs = cut(P, clash)
+                    gids, gtext, goffs = cut(G, clash)
+                    yield pids, ptext, poffs, (gtext, goffs)
+                sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(bad_p, bad_g))
                 sys.exit(1)
-            if m:
-                yield pids[:m], ptext, poffs[:m + 1], (gtext, goffs[:m + 1])
-            if m < len(pids):
-                break
+            pids, ptext, poffs = cut(P, m)
+            gids, gtext, goffs = cut(G, m)
+            yield pids, ptext, poffs, (gtext, goffs)
     _finish_aligner(align_proc, parse_proc)
 
 

@@ -532,3 +532,63 @@ def test_one_process_driving_several_devices(engine, monkeypatch, tmp_path):
         with pytest.raises(ValueError, match="broadcast"):
             sc.classify(TINY, fasta_input=str(fasta), output=str(tmp_path / "never.tsv"), verbose=1, save_ali_to_file=str(saved))
         assert len(saved.read_text().splitlines()) == 40 and not os.path.exists(tmp_path / "never.tsv")
+
+
+def test_protein_and_gene_streams_are_paired_record_by_record(engine, monkeypatch, tmp_path, capsys):
+    """The two FASTA batchers cut their streams independently (a gene file with a line outside ASCII or a lone
+    carriage return is re-parsed and lands in one batch whole): records must still pair up one to one, as
+    the reference's zip() pairs them (align.py:148), and none may be dropped."""
+    from stag_amd import align as sa
+    g, ali = golden_tsv_setup(monkeypatch, tmp_path)
+    taxonomy, tax_function, classifiers = gu.db_from_json(g["db"])
+    rng = np.random.default_rng(44)
+    L = 5 * 18
+    classifiers = {k: (v if isinstance(v, str) else rng.normal(0, 1, size=1 + L)) for k, v in classifiers.items()}
+
+    def fake_load_db(path, protein_fasta_input=None, aligned_sequences=None, dir_output=None):
+        hmm = tempfile.NamedTemporaryFile(delete=False, mode="w")
+        hmm.close()
+        return hmm.name, False, taxonomy, tax_function, classifiers, "0.8.2"
+
+    monkeypatch.setattr(sc, "load_db", fake_load_db)
+    monkeypatch.setattr(sa, "BATCH_RECORDS", 5)
+    n = 23
+    prots, genes, nucs = [], [], []
+    for i in range(n):
+        prot = "".join(rng.choice(list("MKV-"), size=6))
+        res = sum(c != "-" for c in prot)
+        gene = "".join(rng.choice(list("ACGT"), size=3 * res))
+        prots.append(prot)
+        genes.append(gene)
+        nucs.append(oracle_np.protein2gene_alignment("r%d" % i, prot, gene))
+    ids = ["r%d%s" % (i, " café" if i == 3 else "") for i in range(n)]     # the whole header line is the id (helpers.py:112)
+    (tmp_path / "p.a2m").write_bytes("".join(">%s\n%s\n" % (ids[i], p) for i, p in enumerate(prots)).encode("utf-8"))
+    gene_file = tmp_path / "genes.fna"
+    # record 3's header carries a character outside ASCII, record 11 ends in a lone carriage return
+    gene_file.write_bytes("".join(">%s\n%s%s" % (ids[i], s, "\r" if i == 11 else "\n")
+                                  for i, s in enumerate(genes)).encode("utf-8"))
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "hmmalign").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat %s\n" % (tmp_path / "p.a2m"))
+    (bindir / "esl-reformat").write_text("#!/bin/sh\n[ $# -eq 0 ] && exit 0\ncat\n")
+    for t in ("hmmalign", "esl-reformat"):
+        os.chmod(bindir / t, 0o755)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    prot_file = tmp_path / "prot.faa"
+    prot_file.write_text(">unused\nMKV\n")
+    # the batchers do cut differently here
+    with open(gene_file, "rb") as fh:
+        gene_cuts = [len(ids) for ids, _, _ in ingest_batches(fh)]
+    assert gene_cuts != [5, 5, 5, 5, 3] and sum(gene_cuts) == n
+    length, rows = sc.classify("db", fasta_input=str(gene_file), protein_fasta_input=str(prot_file), verbose=1,
+                               output=str(tmp_path / "o"), long_out=True)
+    assert length == L and [r[0] for r in rows] == ids
+    for i, row in enumerate(rows):
+        x, _ = oracle_np.convert_alignment(nucs[i])
+        gu.rows_match(row, oracle_np.classify_seq(ids[i], x, taxonomy, tax_function, classifiers), rtol=RTOL[engine])
+    capsys.readouterr()
+
+
+def ingest_batches(fh):
+    from stag_amd import ingest
+    return ingest.fasta_batches(fh, batch_records=5, text_mode=True)
