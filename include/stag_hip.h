@@ -128,6 +128,30 @@ int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int
 int stag_classify_bits_dev(stag_db_t *db, const uint32_t *d_bits, int64_t n, const int32_t *d_status_in,
                            const stag_results_t *d_out, void *stream);
 
+/*
+ * classify.py:16-20 (alignment_reader) on the GPU, for the lines of a -s file in the form stag itself writes
+ * (-S, classify.py:160-162): after the id, fields that are the single characters '0' / '1' separated by single
+ * tabs.  The caller finds the lines (stag_onehot_lines in stag_ingest.h does, without looking at the fields) and
+ * hands over, per line, its body text[body_begin[i] .. body_end[i]): what follows the id's tab, right-stripped.
+ * Row i (words_per_row words, bit f -> word f>>5, bit f&31) is written when the line has exactly n_features such
+ * fields and is zero otherwise; n_fields[i] = the fields of the line (0 when the body is not of that form);
+ * flag[i] = 1 when the body is not "x<tab>x<tab>...x" with every x in {0, 1}: the reference's int() per field
+ * accepts much more (" 1", "+1", "01", other digits), so such a line is not guessed at -- the caller parses it the
+ * reference's way and supplies the row (patch_rows below).
+ * _dev form: d_text is a 4-byte aligned buffer of text_bytes bytes, text_bytes a multiple of 4 (pad it).
+ */
+int stag_parse_onehot_dev(int32_t n_features, const char *d_text, int64_t text_bytes, const int64_t *d_body_begin,
+                          const int64_t *d_body_end, int64_t n, uint32_t *d_bits, int32_t *d_n_fields,
+                          int32_t *d_flag, void *stream);
+/* Host form, in two steps so that the caller can parse the flagged lines in between: _parse copies the text up,
+ * parses it and leaves the n rows in the handle; _classify overwrites the rows patch_index[j] (j < n_patch) with
+ * patch_rows[j * words_per_row ..], then runs classify.py:94-124 on the n rows as stag_classify_bits does
+ * (status_in as there, e.g. STAG_SEQ_LENGTH_MISMATCH for lines with n_fields != n_features). */
+int stag_onehot_text_parse(stag_db_t *db, const char *text, int64_t text_bytes, const int64_t *body_begin,
+                           const int64_t *body_end, int64_t n, int32_t *n_fields, int32_t *flag);
+int stag_onehot_text_classify(stag_db_t *db, int64_t n, const int64_t *patch_index, const uint32_t *patch_rows,
+                              int64_t n_patch, const int32_t *status_in, const stag_results_t *out);
+
 /* Encode + classify without the rows leaving the GPU.  bits_out (may be NULL) receives the
  * packed rows (for -S, classify.py:160-162).
  * The host form is a pipeline: the batch is cut into sub-batches of 65,536 records whose text

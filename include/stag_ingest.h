@@ -62,6 +62,17 @@ int64_t stag_onehot_parse(const char *buf, int64_t len, int32_t final, int32_t n
                           int64_t max_rows, uint32_t *bits_out, stag_record_t *recs, int64_t *consumed);
 
 /*
+ * classify.py:16-19 without the fields: the lines of a -s file for the GPU parser (stag_parse_onehot_dev /
+ * stag_onehot_text_parse in stag_hip.h).  Same line ends, right-strip and id as stag_onehot_parse; instead of
+ * parsing the fields it reports where they are: body i = buf[body_begin[i] .. body_end[i]) is what follows the
+ * id's tab, right-stripped.  A line the fast path must not take (STAG_INGEST_FALLBACK: it ends in a non-ASCII
+ * byte) and a line without fields get an empty body, which the GPU parser flags for the caller's slow path.
+ * Returns lines written (<= max_rows) or -1 on bad arguments; *consumed: bytes of buf used (whole lines).
+ */
+int64_t stag_onehot_lines(const char *buf, int64_t len, int32_t final, int64_t max_rows, stag_record_t *recs,
+                          int64_t *body_begin, int64_t *body_end, int64_t *consumed);
+
+/*
  * classify.py:160-162: print(id, "\t".join("1"/"0" per feature), sep="\t").  ids are the n strings
  * ids[id_off[i] .. id_off[i+1]).  Returns the bytes written to out, or -(bytes needed) when
  * out_cap is too small.

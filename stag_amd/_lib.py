@@ -49,6 +49,9 @@ EXPORTS = {
                                            ctypes.c_double, c_p, c_p, c_p, c_p, c_p]),
     "stag_classify_bits": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.POINTER(Results)]),
     "stag_classify_bits_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.POINTER(Results), c_p]),
+    "stag_parse_onehot_dev": (ctypes.c_int, [ctypes.c_int32, c_p, ctypes.c_int64, c_p, c_p, ctypes.c_int64, c_p, c_p, c_p, c_p]),
+    "stag_onehot_text_parse": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, c_p, ctypes.c_int64, c_p, c_p]),
+    "stag_onehot_text_classify": (ctypes.c_int, [c_p, ctypes.c_int64, c_p, c_p, ctypes.c_int64, c_p, ctypes.POINTER(Results)]),
     "stag_classify_a2m": (ctypes.c_int, [c_p, c_p, c_p, ctypes.c_int64, ctypes.c_double,
                                          ctypes.POINTER(Results), c_p, c_p]),
     "stag_classify_a2m_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.c_int64, ctypes.c_double,

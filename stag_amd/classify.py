@@ -60,15 +60,32 @@ def _classify_prealigned(pool, aligned_sequences, tagged, state):
     world, rank = parallel.world_rank()
     db = pool.first
     L = db.n_features
-    batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
-                                    slow_line=parse_onehot_line)
     pending = collections.deque()
 
     def finish_oldest():
         b, ids, fut = pending.popleft()
         state["batch"] = b
-        tagged.append((b, db.result_rows(fut.result(), ids, long_out=True)))
+        res = fut.result()
+        tagged.append((b, db.result_rows(res[0] if isinstance(res, tuple) else res, ids, long_out=state["long_rows"])))
 
+    if getattr(db, "classify_onehot_text", None) is not None:
+        # the GPU parses the fields (k_parse_onehot): the host only finds the lines and their ids
+        batches = ingest.onehot_text_batches(aligned_sequences, batch_rows=READER_BATCH, ring_slots=_in_flight(pool) + 2,
+                                             slow_line=parse_onehot_line)
+        for b, (ids, text, bb, be, raw) in enumerate(batches):
+            if not state["alignment_length"]:
+                state["alignment_length"] = len(parse_onehot_line(raw(0))[1])
+            if parallel.owner_of_batch(b, world) != rank:
+                continue
+            pending.append((b, ids, pool.submit(lambda d, t=text, bb=bb, be=be, raw=raw:
+                                                d.classify_onehot_text(t, bb, be, parse_onehot_line, raw))))
+            while len(pending) >= _in_flight(pool):
+                finish_oldest()
+        while pending:
+            finish_oldest()
+        return
+    batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
+                                    slow_line=parse_onehot_line)
     for b, (ids, bits, n_fields) in enumerate(batches):
         if not state["alignment_length"]:
             state["alignment_length"] = int(n_fields[0])
@@ -126,7 +143,8 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
     if verbose > 2:
         sys.stderr.write("Load database: " + str("{0:.2f}".format(time_after_loading - t0)) + " sec\n")
 
-    state = {"alignment_length": None, "batch": 0}
+    # the long fields (14 float reprs per row) are formatted only when they will be printed (classify.py:182-184)
+    state = {"alignment_length": None, "batch": 0, "long_rows": bool(long_out) and not internal_call}
     tagged = []          # (batch index, rows) of the batches this rank classified
     n_pass = n_not_pass = 0
     error = None
@@ -135,7 +153,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
             state["alignment_length"] = int(sum(concat_source["gene_len"]))
             if rank == 0 and len(concat_source["ids"]):
                 res = db.classify_concat(concat_source["gene_len"], concat_source["gene_rows"], concat_source["src_row"])
-                tagged.append((0, db.result_rows(res, concat_source["ids"], long_out=True)))
+                tagged.append((0, db.result_rows(res, concat_source["ids"], long_out=state["long_rows"])))
         elif aligned_sequences:
             _classify_prealigned(pool, aligned_sequences, tagged, state)
         else:
@@ -173,7 +191,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                 if len(passed) and not state["alignment_length"]:
                     state["alignment_length"] = 5 * int(res.n_char[passed[0]])
                 if mine:
-                    tagged.append((b, db.result_rows(res, ids, long_out=True)))
+                    tagged.append((b, db.result_rows(res, ids, long_out=state["long_rows"])))
                 if want_bits and len(passed):      # classify.py:160-162
                     alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed], db.n_features))
                     if packed_rows_out is not None:
@@ -218,7 +236,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
     out_header = OUT_HEADER
     if not long_out or internal_call:
         out_header = out_header[:2]
-        list_to_print = [item[:2] for item in list_to_print]
+        list_to_print = [item[:2] for item in list_to_print]     # (already two fields each, see long_rows)
     if not internal_call:
         try:
             print(*out_header, sep="\t", file=outfile)

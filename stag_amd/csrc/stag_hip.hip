@@ -137,6 +137,7 @@ struct stag_db {
     DevBuf<uint8_t> mfma_ok;
     std::vector<uint8_t> level_has_mfma, level_has_gather;   // per level: are there tasks for either kernel?
     int walk_mode = 0;                                         // 0 auto, 1 gather only (STAG_WALK=gather)
+    int64_t parsed_rows = 0;                                   // rows stag_onehot_text_parse left in `bits`
     DevBuf<unsigned long long> dbg;                            // phase stamps of STAG_ABL == 10 builds
     DevBuf<uint8_t> text, gene_text, bt_text;
     DevBuf<int64_t> offs, gene_offs, bt_begin, bt_end;
@@ -832,6 +833,77 @@ int stag_classify_bits(stag_db_t *db, const uint32_t *bits, int64_t n, const int
         return rc;
     HIP_TRY(hipMemcpy(db->bits.p, bits, (size_t)n * db->W * 4, hipMemcpyHostToDevice));
     if (status_in) HIP_TRY(hipMemcpy(db->enc_status.p, status_in, n * 4, hipMemcpyHostToDevice));
+    if ((rc = walk_dev(db, work_of(db), db->bits.p, n, status_in ? db->enc_status.p : nullptr, resolve(db, nullptr), true, nullptr)))
+        return rc;
+    return copy_results_to_host(db, out, n, nullptr);
+}
+
+int stag_parse_onehot_dev(int32_t n_features, const char *d_text, int64_t text_bytes, const int64_t *d_body_begin,
+                          const int64_t *d_body_end, int64_t n, uint32_t *d_bits, int32_t *d_n_fields, int32_t *d_flag,
+                          void *stream) {
+    if (n < 0 || n_features < 1 || text_bytes < 0 ||
+        (n > 0 && (!d_text || !d_body_begin || !d_body_end || !d_bits || !d_n_fields || !d_flag)))
+        return fail(STAG_E_INVALID, "bad argument");
+    if (n == 0) return STAG_OK;
+    if ((text_bytes & 3) || ((uintptr_t)d_text & 3))
+        return fail(STAG_E_INVALID, "d_text must be 4-byte aligned and text_bytes (the size of the buffer) a multiple of 4: pad the buffer");
+    if ((n + 3) / 4 > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    hipLaunchKernelGGL(k_parse_onehot, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t *)d_text, text_bytes, d_body_begin, d_body_end, n, n_features,
+                       stag_words_per_row(n_features), d_bits, d_n_fields, d_flag);
+    return launch_check("k_parse_onehot");
+}
+
+// The lines' rows stay in the handle (db->bits) for stag_onehot_text_classify.
+int stag_onehot_text_parse(stag_db_t *db, const char *text, int64_t text_bytes, const int64_t *body_begin,
+                           const int64_t *body_end, int64_t n, int32_t *n_fields, int32_t *flag) {
+    if (!db || n < 0 || text_bytes < 0 || (n > 0 && (!text || !body_begin || !body_end || !n_fields || !flag)))
+        return fail(STAG_E_INVALID, "bad argument");
+    db->parsed_rows = 0;
+    if (n == 0) return STAG_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (body_begin[i] < 0 || body_end[i] < body_begin[i] || body_end[i] > text_bytes)
+            return fail(STAG_E_INVALID, "line %lld: body [%lld, %lld) is not inside the text buffer of %lld bytes", (long long)i,
+                        (long long)body_begin[i], (long long)body_end[i], (long long)text_bytes);
+    HIP_TRY(hipSetDevice(db->device));
+    int rc;
+    const int64_t padded = (text_bytes + 15) / 16 * 16;
+    if ((rc = reserve_walk(db, n)) || (rc = db->bits.reserve((size_t)n * db->W)) || (rc = db->enc_status.reserve(n)) ||
+        (rc = db->enc_n_char.reserve(n)) || (rc = db->text.reserve(padded + 16)) || (rc = db->bt_begin.reserve(n)) ||
+        (rc = db->bt_end.reserve(n)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(db->text.p, text, text_bytes, hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemsetAsync(db->text.p + text_bytes, 0, padded - text_bytes, nullptr));
+    HIP_TRY(hipMemcpyAsync(db->bt_begin.p, body_begin, n * sizeof(int64_t), hipMemcpyHostToDevice, nullptr));
+    HIP_TRY(hipMemcpyAsync(db->bt_end.p, body_end, n * sizeof(int64_t), hipMemcpyHostToDevice, nullptr));
+    // n_fields -> enc_n_char, flag -> enc_status (overwritten with the caller's status by stag_onehot_text_classify)
+    if ((rc = stag_parse_onehot_dev(db->L, (const char *)db->text.p, padded, db->bt_begin.p, db->bt_end.p, n, db->bits.p,
+                                    db->enc_n_char.p, db->enc_status.p, nullptr)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(n_fields, db->enc_n_char.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipMemcpyAsync(flag, db->enc_status.p, n * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    db->parsed_rows = n;
+    return STAG_OK;
+}
+
+int stag_onehot_text_classify(stag_db_t *db, int64_t n, const int64_t *patch_index, const uint32_t *patch_rows,
+                              int64_t n_patch, const int32_t *status_in, const stag_results_t *out) {
+    if (!db || n < 0 || n_patch < 0 || !out || (n > 0 && !out->status) || (n_patch > 0 && (!patch_index || !patch_rows)))
+        return fail(STAG_E_INVALID, "bad argument");
+    if (n != db->parsed_rows)
+        return fail(STAG_E_INVALID, "stag_onehot_text_classify: %lld rows asked for, stag_onehot_text_parse left %lld",
+                    (long long)n, (long long)db->parsed_rows);
+    db->parsed_rows = 0;
+    if (n == 0) return STAG_OK;
+    HIP_TRY(hipSetDevice(db->device));
+    for (int64_t j = 0; j < n_patch; ++j) {
+        if (patch_index[j] < 0 || patch_index[j] >= n) return fail(STAG_E_INVALID, "patch_index[%lld] out of range", (long long)j);
+        HIP_TRY(hipMemcpyAsync(db->bits.p + (size_t)patch_index[j] * db->W, patch_rows + (size_t)j * db->W,
+                               (size_t)db->W * 4, hipMemcpyHostToDevice, nullptr));
+    }
+    if (status_in) HIP_TRY(hipMemcpyAsync(db->enc_status.p, status_in, n * 4, hipMemcpyHostToDevice, nullptr));
+    int rc;
     if ((rc = walk_dev(db, work_of(db), db->bits.p, n, status_in ? db->enc_status.p : nullptr, resolve(db, nullptr), true, nullptr)))
         return rc;
     return copy_results_to_host(db, out, n, nullptr);

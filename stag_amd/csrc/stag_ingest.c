@@ -163,6 +163,46 @@ int64_t stag_onehot_parse(const char *buf, int64_t len, int32_t final, int32_t n
     return n;
 }
 
+int64_t stag_onehot_lines(const char *buf, int64_t len, int32_t final, int64_t max_rows, stag_record_t *recs,
+                          int64_t *body_begin, int64_t *body_end, int64_t *consumed) {
+    if (!buf || len < 0 || max_rows < 0 || !recs || !body_begin || !body_end || !consumed) return -1;
+    int64_t n = 0, pos = 0;
+    *consumed = 0;
+    while (pos < len && n < max_rows) {
+        /* the same line ends as stag_onehot_parse: the first '\n' or '\r' */
+        const char *a = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
+        const int64_t lim = a ? (int64_t)(a - buf) : len;
+        const char *b = (const char *)memchr(buf + pos, '\r', (size_t)(lim - pos));
+        const int64_t e = b ? (int64_t)(b - buf) : lim;
+        int64_t next;
+        if (e >= len) {
+            if (!final) break;
+            next = len;
+        } else if (buf[e] == '\r') {
+            if (e + 1 < len) next = buf[e + 1] == '\n' ? e + 2 : e + 1;
+            else if (final) next = len;
+            else break;
+        } else {
+            next = e + 1;
+        }
+        int fb = 0;
+        const int64_t le = rstrip_end(buf, pos, e, &fb);
+        const char *tab = (const char *)memchr(buf + pos, '\t', (size_t)(le - pos));
+        const int64_t id_end = tab ? (int64_t)(tab - buf) : le;
+        stag_record_t *r = &recs[n];
+        r->raw_begin = pos; r->raw_end = next; r->pad = 0; r->n_fields = 0;
+        r->id_begin = pos; r->id_len = id_end - pos;
+        r->flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK;
+        /* a flagged line, or one without fields, gets an empty body: the device parser flags it in turn */
+        body_begin[n] = (tab && !fb) ? id_end + 1 : le;
+        body_end[n] = le;
+        ++n;
+        pos = next;
+        *consumed = pos;
+    }
+    return n;
+}
+
 int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, int32_t words_per_row,
                            const char *ids, const int64_t *id_off, char *out, int64_t out_cap) {
     if (!bits || n < 0 || n_features < 0 || !ids || !id_off || (!out && out_cap > 0)) return -1;

@@ -468,6 +468,74 @@ __global__ __launch_bounds__(256) void k_backtranslate(const uint8_t *__restrict
     if (lane == 0) { out_begin[rec] = o0; out_end[rec] = o0 + emitted; status[rec] = 0; }
 }
 
+// ------------------------------------------------------------------------------------------
+// -s lines: stag/classify.py:16-20 (alignment_reader) for lines in the form stag itself writes (-S,
+// classify.py:160-162): after the id, fields that are the single characters '0' / '1', separated by single tabs.
+// body = text[body_begin, body_end): the line after the id's tab, right-stripped (the host finds the lines; it does
+// not look at the fields).  One wave per line; per step lane l takes 64 bytes = 32 fields = one word of the row.
+//   n_fields = fields of the line (0 when the body is not of that form)
+//   flag     = 1: the body is not "x<tab>x<tab>...x" with every x in {0, 1} -> the caller parses the line the
+//              reference's way (int() per field) and supplies the row; 0: row written (all zero when n_fields != L,
+//              such a row is never classified)
+// The text buffer must be readable up to the next multiple of 4 after every body_end.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_parse_onehot(const uint8_t *__restrict__ text, int64_t text_bytes,
+                                                      const int64_t *__restrict__ body_begin,
+                                                      const int64_t *__restrict__ body_end, int64_t n, int L, int W,
+                                                      uint32_t *__restrict__ rows, int32_t *__restrict__ n_fields,
+                                                      int32_t *__restrict__ flag) {
+    const int lane = threadIdx.x & 63;
+    const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (line >= n) return;
+    const int64_t b = body_begin[line], e = body_end[line];
+    const int64_t blen = e - b;                  // "x\tx\t...x": 2 nf - 1 bytes
+    const bool form = b >= 0 && e <= text_bytes && blen > 0 && (blen & 1) && (blen + 1) / 2 <= 0x7fffffff;
+    const int64_t nf = form ? (blen + 1) / 2 : 0;
+    const bool takes = form && nf == L;
+    uint32_t *row = rows + (size_t)line * W;
+    constexpr uint32_t PAT = 0x09300930u;        // '0' <tab> '0' <tab>, little endian
+    uint32_t bad = 0;
+    if (form) {
+        const int64_t words = (blen + 64) / 64;  // words of 32 fields the body touches
+        const int64_t w_end = takes && W > words ? (int64_t)W : words;   // (a row is padded to a multiple of 4 words)
+        for (int64_t w0 = 0; w0 < w_end; w0 += 64) {
+            const int64_t w = w0 + lane;
+            const int64_t pos = b + 64 * w;      // first byte of this lane's 32 fields
+            uint32_t word = 0;
+            if (w < words) {
+                const int64_t base = pos & ~(int64_t)3;
+                const int sh = (int)(pos & 3);
+                uint32_t d[17];
+#pragma unroll
+                for (int i = 0; i < 17; ++i) {   // aligned dwords that hold bytes of the body
+                    const int64_t at = base + 4 * i;
+                    d[i] = at < e ? *reinterpret_cast<const uint32_t *>(text + at) : 0u;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    // the 4 bytes at pos + 4 i; v_alignbyte: bytes sh .. sh + 3 of the pair
+                    uint32_t x = __builtin_amdgcn_alignbyte(d[i + 1], d[i], (uint32_t)sh);
+                    const int64_t left = e - (pos + 4 * i);          // bytes of the body from here on
+                    if (left < 4) {              // past the body: as if the line went on with "0\t0\t..."
+                        const uint32_t keep = left <= 0 ? 0u : (1u << (8 * (int)left)) - 1u;
+                        x = (x & keep) | (PAT & ~keep);
+                    }
+                    bad |= (x & 0xfffefffeu) ^ PAT;
+                    word |= ((x & 1u) | ((x >> 15) & 2u)) << (2 * i);
+                }
+            }
+            if (takes && w < W) row[w] = word;
+        }
+    }
+    const bool any_bad = __ballot(bad != 0u) != 0ull;
+    if (!takes || any_bad)
+        for (int w = lane; w < W; w += 64) row[w] = 0u;
+    if (lane == 0) {
+        n_fields[line] = (int32_t)nf;
+        flag[line] = (!form || any_bad) ? 1 : 0;
+    }
+}
+
 // find_n_aligned_characters (classify.py:79-87) and the R0 window for rows that did not come
 // from k_encode_a2m.
 __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restrict__ rows, int64_t n, int L, int W,
@@ -968,7 +1036,10 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     const bool one_slice = wB - wA <= WCAP_CHUNKS;            // the usual case: staged once for all siblings
 
     // ---- LDS layout of this task
-    const int stride = one_slice ? (((wB - wA) * CHUNK_WORDS) | 1) : ROW_STRIDE;
+    // (wider windows go slice by slice, WIDE_SLICE_CHUNKS at a time: narrower slices than the buffer could hold, so
+    // that each wave's piece holds the slice's coefficients of TWO siblings, fetched together with the rows)
+    constexpr int WIDE_SLICE_CHUNKS = 3;
+    const int stride = one_slice ? (((wB - wA) * CHUNK_WORDS) | 1) : (WIDE_SLICE_CHUNKS * CHUNK_WORDS) | 1;
     const int ent_base_words = (TILE * stride + 3) & ~3;
     const int piece = (WALK_LDS_WORDS - ent_base_words) / (4 * NW);      // entries per wave
     const int half = min(piece >> 1, 64) & ~3;                          // entries per buffer: one DMA (one per lane) fills it
@@ -1135,20 +1206,28 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                 zz[j] = 0.0;
                 if (pg0 + j * NW + wave < k) zz[j] = gap_consts(c0 + pg0 + j * NW + wave);
             }
-            for (int sA = wA; sA < wB; sA += WCAP_CHUNKS) {
-                const int sB = min(wB, sA + WCAP_CHUNKS);
-                __syncthreads();   // everyone is done reading the previous slice
+            for (int sA = wA; sA < wB; sA += WIDE_SLICE_CHUNKS) {
+                const int sB = min(wB, sA + WIDE_SLICE_CHUNKS);
+                uint32_t e_lo[PG], e_hi[PG];
+#pragma unroll
+                for (int j = 0; j < PG; ++j) {
+                    e_lo[j] = e_hi[j] = 0;
+                    if (pg0 + j * NW + wave < k) {   // wave-uniform
+                        const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
+                        e_lo[j] = bo[sA] * BLOCK_ENTRIES;
+                        e_hi[j] = bo[sB] * BLOCK_ENTRIES;
+                    }
+                }
+                __syncthreads();   // everyone is done reading the previous slice (rows and coefficients)
                 stage_rows(sA, sB);
+#pragma unroll
+                for (int j = 0; j < PG; ++j) fetch_ent(e_lo[j], e_hi[j], j);   // in flight together with the rows
                 __syncthreads();   // DMA drained, rows visible
 #pragma unroll
                 for (int j = 0; j < PG; ++j) {
-                    if (pg0 + j * NW + wave < k) {   // wave-uniform
+                    if (pg0 + j * NW + wave < k) {
                         const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
-                        const uint32_t e_lo = bo[sA] * BLOCK_ENTRIES, e_hi = bo[sB] * BLOCK_ENTRIES;
-                        lds_reads_done();            // wave-private piece, after the previous sibling's reads
-                        fetch_ent(e_lo, e_hi, 0);
-                        dma_wait();
-                        score_slice(zz[j], bo, e_lo, e_hi, sA, sB, 0);
+                        score_slice(zz[j], bo, e_lo[j], e_hi[j], sA, sB, j);
                     }
                 }
             }

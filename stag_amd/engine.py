@@ -129,6 +129,37 @@ class Database:
         res.level_prob = res.level_prob[:, :self.n_keys]
         return res
 
+    def classify_onehot_text(self, text, body_begin, body_end, slow_line=None, raw=None):
+        """alignment_reader + classify_seq (classify.py:16-20, 94-124) for lines of a -s file found by
+        stag_amd.ingest.onehot_text_batches: the GPU parses the fields.  Lines it flags (fields other than the
+        single characters 0 / 1) go through slow_line(raw(i)) -> (id, bool array), the reference's int() per field.
+        Returns (result, n_fields)."""
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        bb = np.ascontiguousarray(body_begin, dtype=np.int64)
+        be = np.ascontiguousarray(body_end, dtype=np.int64)
+        n = len(bb)
+        n_fields = np.zeros(n, dtype=np.int32)
+        flag = np.zeros(n, dtype=np.int32)
+        _lib.check(_lib.lib().stag_onehot_text_parse(self.handle, _lib.ptr(text), len(text), _lib.ptr(bb), _lib.ptr(be), n,
+                                                     _lib.ptr(n_fields), _lib.ptr(flag)))
+        slow = np.flatnonzero(flag)
+        patch_rows = np.zeros((len(slow), self.words_per_row), dtype=np.uint32)
+        for j, i in enumerate(slow):
+            if slow_line is None or raw is None:
+                raise ValueError("line %d needs the slow path and none was given" % int(i))
+            _, x = slow_line(raw(int(i)))
+            n_fields[i] = len(x)
+            if len(x) == self.n_features:
+                patch_rows[j] = pack_bool_rows(np.asarray(x, dtype=bool)[None, :], self.words_per_row)[0]
+        status = np.where(n_fields == self.n_features, _lib.SEQ_OK, _lib.SEQ_LENGTH_MISMATCH).astype(np.int32)
+        res = BatchResult(n, self.max_depth, self.n_keys)
+        st = res.as_struct()
+        idx = np.ascontiguousarray(slow, dtype=np.int64)
+        _lib.check(_lib.lib().stag_onehot_text_classify(self.handle, n, _lib.ptr(idx), _lib.ptr(patch_rows), len(slow),
+                                                        _lib.ptr(status), ctypes.byref(st)))
+        res.level_prob = res.level_prob[:, :self.n_keys]
+        return res, n_fields
+
     def classify_onehot(self, X):
         """X: bool [n, L] exactly as the reference holds it."""
         X = np.asarray(X)
@@ -261,4 +292,30 @@ class Database:
         """Rows for every sequence the reference would have yielded (status FILTERED is skipped);
         raises the reference's exception for the first failing sequence."""
         raise_for_status(res.status, ids)
-        return [self.result_row(res, i, ids[i], long_out) for i in range(res.n) if res.status[i] == _lib.SEQ_OK]
+        ok = np.flatnonzero(res.status == _lib.SEQ_OK).tolist()
+        if not long_out:
+            return [self.result_row(res, i, ids[i], False) for i in ok]
+        # the long fields of a whole batch: every float goes through repr() in one pass over flat lists (the same
+        # strings as result_row's repr(float(p)); a row then only slices and joins)
+        D, K = res.path_prob.shape[1], len(self.keys)
+        perc_all = list(map(repr, res.path_prob.ravel().tolist()))
+        level_all = list(map(repr, res.level_prob[:, :K].ravel().tolist()))
+        prefix = [k + ":" for k in self.keys]
+        n_aligned = list(map(str, res.n_aligned.tolist()))
+        path_len, lead_all, sel_all = res.path_len.tolist(), res.n_lead_single.tolist(), res.selected.tolist()
+        last = np.maximum(res.path_len.astype(np.int64) - 1, 0)
+        end_all = res.path_node[np.arange(res.n), last].tolist() if D else [-1] * res.n
+        rows = []
+        joined = {}       # (end position, selected) -> the two lineage strings: a position fixes its path
+        for i in ok:
+            n, lead, sel = path_len[i], lead_all[i], sel_all[i]
+            selected = self.keys[sel] if sel >= 0 else -1
+            key = (end_all[i] if n else -1, sel)
+            both = joined.get(key)
+            if both is None:
+                tax = self.lineage(res, i)
+                both = joined[key] = (";".join(tax[0:int(selected) + 1]), "/".join(tax))
+            perc = ["1"] * min(lead, n) + perc_all[i * D + lead:i * D + n]
+            per_level = map(str.__add__, prefix, level_all[i * K:(i + 1) * K])
+            rows.append([ids[i], both[0], both[1], selected, "/".join(perc), "/".join(per_level), n_aligned[i]])
+        return rows

@@ -6,6 +6,8 @@ formats that feed it and the writer for the one it emits, bound from libstag_ing
                   (stag/align.py:139-147) -> (ids, text uint8, offs int64) batches ready for
                   stag_classify_a2m: no Python string per record
   onehot_batches  stag/classify.py:16-20 alignment_reader -> (ids, packed rows, n_fields) batches
+  onehot_text_batches  the same lines found but not parsed: (ids, text, body ranges, raw lines) batches for the
+                  GPU parser (engine.Database.classify_onehot_text)
   format_onehot   stag/classify.py:160-162, the -S lines
 
 Records the C fast path cannot reproduce byte for byte are flagged by it and re-parsed here the
@@ -33,6 +35,7 @@ EXPORTS = {
                                          c_p, ctypes.c_int64, ctypes.c_int64, c_p, c_p, c_p, c_p]),
     "stag_onehot_parse": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int64, c_p, c_p, c_p]),
+    "stag_onehot_lines": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, c_p, c_p, c_p, c_p]),
     "stag_onehot_format": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_p, c_p, c_p,
                                             ctypes.c_int64]),
 }
@@ -234,6 +237,78 @@ def onehot_batches(path, n_features, words_per_row, batch_rows=1 << 14, chunk_by
                 yield ids, bits, n_fields
                 pos += consumed.value
             pending = buf[pos:]
+
+
+class _PinnedRing:
+    """Page-locked byte buffers used in turn (pageable arrays when the GPU library cannot give such memory)."""
+
+    def __init__(self, slots, nbytes):
+        self.bufs, self.turn = [], 0
+        for _ in range(max(slots, 2)):
+            try:
+                from . import _lib
+                keep = _lib.PinnedArray(nbytes, np.uint8)
+                self.bufs.append((keep, keep.a))
+            except Exception:
+                self.bufs.append((None, np.empty(nbytes, dtype=np.uint8)))
+
+    def next(self):
+        self.turn = (self.turn + 1) % len(self.bufs)
+        return self.bufs[self.turn][1]
+
+
+def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 27, ring_slots=3, slow_line=None):
+    """Yields (ids, text, body_begin, body_end, raw) for the lines of a -s file WITHOUT parsing their fields:
+    text is a uint8 view (of a page-locked buffer, valid until ring_slots - 1 further batches have been produced)
+    that holds whole lines, line i's fields are text[body_begin[i]:body_end[i]] (see stag_onehot_lines), and
+    raw(i) returns line i as the str the reference would iterate over (for the slow path).  A batch is the whole
+    lines of one chunk of the file, at most batch_rows of them.  slow_line(str) -> (id, bool array) names the
+    lines the line finder flags (they end in a non-ASCII byte, which may be white space for str.rstrip)."""
+    L = lib()
+    cap = max(int(chunk_bytes), 1 << 16)
+    ring = _PinnedRing(ring_slots, cap)
+    with open(path, "rb") as fh:
+        buf, have, ended = ring.next(), 0, False
+        while True:
+            if not ended:
+                have, ended = _fill(fh, buf[:cap - 16], have)     # (16 bytes stay free: the GPU's copy is padded)
+            pos = 0
+            while pos < have:
+                recs = np.zeros(batch_rows, dtype=RECORD)
+                bb = np.zeros(batch_rows, dtype=np.int64)
+                be = np.zeros(batch_rows, dtype=np.int64)
+                consumed = ctypes.c_int64(0)
+                view = buf[pos:have]
+                n = L.stag_onehot_lines(_ptr(view), len(view), int(ended), batch_rows, _ptr(recs), _ptr(bb), _ptr(be),
+                                        ctypes.byref(consumed))
+                if n < 0:
+                    raise ValueError("stag_onehot_lines: bad arguments")
+                if n == 0:
+                    break             # the rest of the buffer is an incomplete line
+                recs = recs[:n]
+                text = view[:consumed.value]
+                mv = memoryview(text)
+                begins = recs["id_begin"].tolist()
+                ends = (recs["id_begin"] + recs["id_len"]).tolist()
+                ids = [str(mv[b:e], "utf-8") for b, e in zip(begins, ends)]
+
+                def raw(i, mv=mv, rb=recs["raw_begin"], re_=recs["raw_end"]):
+                    return str(mv[int(rb[i]):int(re_[i])], "utf-8")
+
+                for i in np.flatnonzero(recs["flag"] == FALLBACK):
+                    ids[i] = slow_line(raw(int(i)))[0]
+                yield ids, text, bb[:n], be[:n], raw
+                pos += consumed.value
+            rest = have - pos
+            if ended:
+                if rest:
+                    raise ValueError("unparsed bytes at the end of %s" % path)    # (the line finder takes everything)
+                return
+            if pos == 0 and have >= cap - 16:
+                raise ValueError("a line of %s is longer than the read buffer (%d bytes)" % (path, cap))
+            nxt = ring.next()         # the incomplete line moves to the front of the next buffer
+            nxt[:rest] = buf[pos:have]
+            buf, have = nxt, rest
 
 
 def format_onehot(ids, bits, n_features):

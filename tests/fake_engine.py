@@ -19,6 +19,8 @@ class OracleDatabase(Database):
         self._lineage_cache = {}
         self._h = None
 
+    classify_onehot_text = None     # no device parser here: classify() then reads -s files with ingest.onehot_batches
+
     def close(self):
         pass
 
