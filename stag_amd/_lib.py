@@ -120,24 +120,32 @@ def device_count():
     return n.value
 
 
+class _PinnedBlock:
+    """One stag_host_alloc allocation; freed when the last array over it is gone."""
+
+    def __init__(self, nbytes):
+        self.p = lib().stag_host_alloc(nbytes)
+        if not self.p:
+            raise StagError("stag_host_alloc(%d) failed: %s" % (nbytes, lib().stag_last_error().decode()))
+
+    def __del__(self):
+        try:
+            if self.p:
+                lib().stag_host_free(self.p)
+                self.p = None
+        except Exception:
+            pass
+
+
 class PinnedArray:
     """A NumPy array over page-locked host memory from stag_host_alloc: buffers of this kind let the host
-    entry points copy by DMA beside the kernels.  .a is the array; the memory lives as long as this object."""
+    entry points copy by DMA beside the kernels.  .a is the array.  The memory belongs to the array and its
+    views (array -> ctypes buffer -> block): it is freed when the last of them is gone, not when this object is."""
 
     def __init__(self, shape, dtype):
         shape = (shape,) if np.isscalar(shape) else tuple(shape)
         self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
-        self._p = lib().stag_host_alloc(max(self.nbytes, 16))
-        if not self._p:
-            raise StagError("stag_host_alloc(%d) failed: %s" % (self.nbytes, lib().stag_last_error().decode()))
-        buf = (ctypes.c_uint8 * max(self.nbytes, 16)).from_address(self._p)
+        block = _PinnedBlock(max(self.nbytes, 16))
+        buf = (ctypes.c_uint8 * max(self.nbytes, 16)).from_address(block.p)
+        buf._stag_block = block          # every view of the array keeps `buf` alive, `buf` keeps the block
         self.a = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-
-    def __del__(self):
-        try:
-            if self._p:
-                self.a = None
-                lib().stag_host_free(self._p)
-                self._p = None
-        except Exception:
-            pass

@@ -125,6 +125,10 @@ __device__ __forceinline__ uint32_t r0_word(int w, int L) {
     return v;
 }
 
+// 0xff in every byte of h80 that has its top bit set (h80 holds nothing but top bits): (h80 >> 7) * 0xff without the
+// quarter-rate 32-bit multiply
+__device__ __forceinline__ uint32_t byte_mask(uint32_t h80) { return (h80 << 1) - (h80 >> 7); }
+
 // keep[lo_cut * 17 + hi_cut]: byte mask (4 dwords) of the bytes [lo_cut, hi_cut) of a 16-byte vector --
 // the part of a record's first / last vector that belongs to the record.
 struct KeepLut {
@@ -143,7 +147,7 @@ constexpr KeepLut make_keep_lut() {
             }
     return t;
 }
-__device__ const KeepLut KEEP_LUT = make_keep_lut();
+__device__ __attribute__((aligned(16))) const KeepLut KEEP_LUT = make_keep_lut();
 
 // Reductions inside each record's group of G lanes with DPP moves; the result is valid in the
 // group's LAST lane (gl == G - 1).
@@ -214,7 +218,11 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     for (int w = gl * 4; w < W; w += 4 * G) *reinterpret_cast<uint4 *>(row + w) = make_uint4(0u, 0u, 0u, 0u);
     int w_lo = 0x7fffffff, w_hi = 0;     // words this lane changes
 
-    const int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
+    // a record is clamped to the text buffer once, here: the loads below then need no bounds test of their own (a
+    // 16-byte vector that starts before the record's end ends inside the buffer, whose size is a multiple of 16)
+    int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
+    begin = max(begin, (int64_t)0);
+    end = max(min(end, text_bytes), begin);
     const int64_t base = begin & ~(int64_t)15;
     int running = 0, aligned = 0;
     // Positions inside the loop are 32-bit and relative to the record's first byte (a record is
@@ -227,14 +235,22 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     // the vector's bytes that belong to the record: [lo_cut, hi_cut) of 16 (all ones except in a record's first and
     // last vector).
     constexpr int VPL = 2, STEP = 16 * VPL * G;  // bytes of a record per step
-    auto load16 = [&](int64_t p, int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (rel < len && p >= 0 && p + 16 <= text_bytes) v = *reinterpret_cast<const uint4 *>(text + p);
+    // where the record's last 16-byte vector starts, relative to the record's first byte (a multiple of 16 from
+    // -lead).  src = the address of relative position 0; an empty record has nothing in the buffer that is safe to
+    // read (it may sit at the buffer's very end): its lanes fetch 16 bytes of a constant instead.
+    const int last_rel = ((max(len, 1) - 1 + lead) & ~15) - lead;
+    const uint8_t *const src = len > 0 ? text + begin : reinterpret_cast<const uint8_t *>(KEEP_LUT.m) + lead;
+    auto load16 = [&](int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
+        // a vector past the record's end is fetched from the record's last vector instead (no branch, no
+        // zero-fill; its keep mask is all zero, so what it holds does not matter)
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + min(rel, last_rel));
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-        const int lo_cut = min(16, max(0, -rel));
-        const int hi_cut = min(16, max(0, len - rel));
         uint4 q = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-        if (lo_cut > 0 || hi_cut < 16) q = *reinterpret_cast<const uint4 *>(KEEP_LUT.m[lo_cut * 17 + hi_cut]);
+        if (rel < 0 || rel + 16 > len) {     // the record's first / last vector, or one past its end
+            const int lo_cut = min(16, max(0, -rel));
+            const int hi_cut = min(16, max(0, len - rel));
+            q = *reinterpret_cast<const uint4 *>(KEEP_LUT.m[lo_cut * 17 + hi_cut]);
+        }
         k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
     };
     // one vector: its bytes' (one-hot group ^ gap group) in code, the skipped bytes in skip80, A/C/G/T/U counted
@@ -254,7 +270,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             const uint32_t oneh = __builtin_amdgcn_perm(0x04000202u, 0x08001000u, sel);
             const uint32_t y = x ^ expc;
             const uint32_t eq80 = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;  // byte == expected
-            const uint32_t eqm = (eq80 >> 7) * 0xffu;
+            const uint32_t eqm = byte_mask(eq80);
             code[j] = (oneh ^ 0x01010101u) & eqm;   // group ^ gap group: zero for anything that is not A/C/G/T/U
             aligned += __popc(eq80);
         }
@@ -274,7 +290,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         int cnt[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t c = code[j] & ~((skip80[j] >> 7) * 0xffu);
+            const uint32_t c = code[j] & ~byte_mask(skip80[j]);
             const uint32_t k0 = ((skip80[j] >> 7) & 1u) ^ 1u, k1 = ((skip80[j] >> 15) & 1u) ^ 1u;
             const uint32_t k2 = ((skip80[j] >> 23) & 1u) ^ 1u, k3 = (skip80[j] >> 31) ^ 1u;
             const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
@@ -286,20 +302,13 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         hi = pk[3] >> min(64 - sh3, 31);   // the part of pk[3] (20 bits) beyond bit 63
         return cnt[0] + cnt[1] + cnt[2] + cnt[3];
     };
-    uint32_t nxt[VPL][4], nxt_keep[VPL][4];
-    int64_t p = base + (int64_t)gl * (16 * VPL);     // this lane's first vector of the current step
-#pragma unroll
-    for (int v = 0; v < VPL; ++v) load16(p + 16 * v, gl * (16 * VPL) + 16 * v - lead, nxt[v], nxt_keep[v]);
-    for (int rel0 = -lead; __ballot(rel0 < len) != 0ull; rel0 += STEP, p += STEP) {
+    // one step on the vectors wv / keep (fetched during the step before); the next step's go to nxt / nxt_keep
+    auto step = [&](const uint32_t (&wv)[VPL][4], const uint32_t (&keep)[VPL][4], uint32_t (&nxt)[VPL][4],
+                    uint32_t (&nxt_keep)[VPL][4], const int rel0) {
         const int rel = rel0 + gl * (16 * VPL);  // of the lane's first vector; negative only in the first step
-        uint32_t wv[VPL][4], keep[VPL][4];
-#pragma unroll
-        for (int v = 0; v < VPL; ++v)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { wv[v][j] = nxt[v][j]; keep[v][j] = nxt_keep[v][j]; }
 #pragma unroll
         for (int v = 0; v < VPL; ++v)            // the next vectors are in flight while these are encoded
-            load16(p + STEP + 16 * v, rel + STEP + 16 * v, nxt[v], nxt_keep[v]);
+            load16(rel + STEP + 16 * v, nxt[v], nxt_keep[v]);
         // Aligned amplicon reads are mostly runs of '-': when every valid byte of every lane is a
         // gap, the step's output is a prefix of a constant bit pattern (bit 0 of each column).
         uint32_t not_gap = 0u;
@@ -311,7 +320,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
             // the row already says "gap" everywhere: only the column count moves on, by the bytes
             // of this step that belong to the record
             running += max(0, min(len, rel0 + STEP) - max(0, rel0));
-            continue;
+            return;
         }
         uint32_t code[VPL][4], skip80[VPL][4];
         uint32_t any_skip = 0u;
@@ -357,6 +366,18 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
 #pragma unroll
         for (int v = 0; v < VPL; ++v) emit_groups(row, W, at[v], lo[v], hi[v], w_lo, w_hi);
         running += total;
+    };
+    // two register sets used in turn, so that no step starts by copying the prefetched vectors
+    uint32_t wa[VPL][4], ka[VPL][4], wb[VPL][4], kb[VPL][4];
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) load16(gl * (16 * VPL) + 16 * v - lead, wa[v], ka[v]);
+    for (int rel0 = -lead;;) {
+        if (__ballot(rel0 < len) == 0ull) break;
+        step(wa, ka, wb, kb, rel0);
+        rel0 += STEP;
+        if (__ballot(rel0 < len) == 0ull) break;
+        step(wb, kb, wa, ka, rel0);
+        rel0 += STEP;
     }
     // totals over the record's lanes: valid in the group's last lane, which writes the record's scalars
     aligned = group_reduce_last<G>(aligned, 0, [](int x, int y) { return x + y; });

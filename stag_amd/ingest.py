@@ -265,7 +265,7 @@ def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 27, ring_slot
     lines of one chunk of the file, at most batch_rows of them.  slow_line(str) -> (id, bool array) names the
     lines the line finder flags (they end in a non-ASCII byte, which may be white space for str.rstrip)."""
     L = lib()
-    cap = max(int(chunk_bytes), 1 << 16)
+    cap = max(int(chunk_bytes), 64)
     ring = _PinnedRing(ring_slots, cap)
     with open(path, "rb") as fh:
         buf, have, ended = ring.next(), 0, False

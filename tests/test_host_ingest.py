@@ -235,3 +235,73 @@ def test_fasta_batches_in_the_two_buffer_ring_equal_plain_batches():
         prev = (text, k)
         count += 1
     assert count == len(plain) and count > 5
+
+
+def lines_of(path, chunk, batch_rows=7):
+    """[(id, fields as text or None)] from the line finder that feeds the GPU parser."""
+    out = []
+    for ids, text, bb, be, raw in ingest.onehot_text_batches(path, batch_rows=batch_rows, chunk_bytes=chunk,
+                                                             slow_line=parse_onehot_line):
+        assert len(ids) == len(bb) == len(be) <= batch_rows
+        for i, gid in enumerate(ids):
+            out.append((gid, bytes(text[bb[i]:be[i]]).decode("utf-8"), raw(i)))
+    return out
+
+
+@pytest.mark.parametrize("name", sorted(G["onehot"]))
+@pytest.mark.parametrize("chunk", [64, 100, 1 << 20])
+def test_onehot_line_finder_matches_reference(tmp_path, name, chunk):
+    """stag_onehot_lines: the ids are the reference's, and a line's body is its fields joined by tabs whenever the
+    line is one the device parser may take (single-character fields); the slow path gets the line itself."""
+    case = G["onehot"][name]
+    data = bytes.fromhex(case["hex"])
+    path = tmp_path / "in.tsv"
+    path.write_bytes(data)
+    with open(path, "r") as fh:
+        ref_lines = list(fh)
+    if max((len(l.encode("utf-8")) for l in ref_lines), default=0) > chunk - 16:
+        with pytest.raises(ValueError):
+            lines_of(str(path), chunk)
+        return
+    if case["raises"]:
+        try:
+            got = lines_of(str(path), chunk)
+        except ValueError:       # (a flagged line whose field is not an integer: named by the slow path)
+            return
+    else:
+        got = lines_of(str(path), chunk)
+        assert [g[0] for g in got] == [r[0] for r in case["rows"]]
+    assert [g[2].rstrip() for g in got] == [l.rstrip() for l in ref_lines]
+    for gid, body, line in got:
+        fields = line.rstrip().split("\t")[1:]
+        if body:
+            assert body == "\t".join(fields) and gid == line.rstrip().split("\t")[0]
+
+
+def test_onehot_line_finder_random_files(tmp_path):
+    rng = np.random.default_rng(77)
+    pieces = [b"0", b"1", b"\t", b"\t", b"\n", b"\r\n", b"\r", b"id", b" ", b"2", b"\xc3\xa9", b"\xc2\xa0", b"x", b"\x0b"]
+    path = tmp_path / "s.tsv"
+    for case in range(600):
+        data = b"".join(pieces[int(i)] for i in rng.integers(0, len(pieces), size=int(rng.integers(0, 40))))
+        path.write_bytes(data)
+        with open(path, "r") as fh:
+            ref_lines = list(fh)
+        try:
+            want_ids = [parse_onehot_line(l)[0] for l in ref_lines]
+        except ValueError:
+            want_ids = None
+        for chunk in (64, 4096):
+            if max((len(l.encode("utf-8")) for l in ref_lines), default=0) > chunk - 16:
+                continue
+            try:
+                got = lines_of(str(path), chunk, batch_rows=int(rng.choice([1, 3, 100])))
+            except ValueError:       # a flagged line whose field is not an integer: the reference raises there too
+                assert want_ids is None, (case, data)
+                continue
+            assert [g[2].rstrip() for g in got] == [l.rstrip() for l in ref_lines], (case, data)
+            if want_ids is not None:
+                assert [g[0] for g in got] == want_ids, (case, data)
+            for gid, body, line in got:
+                if body:
+                    assert body == "\t".join(line.rstrip().split("\t")[1:]), (case, data)
