@@ -291,11 +291,14 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t c = code[j] & ~byte_mask(skip80[j]);
-            const uint32_t k0 = ((skip80[j] >> 7) & 1u) ^ 1u, k1 = ((skip80[j] >> 15) & 1u) ^ 1u;
-            const uint32_t k2 = ((skip80[j] >> 23) & 1u) ^ 1u, k3 = (skip80[j] >> 31) ^ 1u;
-            const uint32_t s1 = 5u * k0, s2 = 5u * (k0 + k1), s3 = 5u * (k0 + k1 + k2);
-            pk[j] = (c & 0x1fu) | (((c >> 8) & 0x1fu) << s1) | (((c >> 16) & 0x1fu) << s2) | ((c >> 24) << s3);
-            cnt[j] = (int)(k0 + k1 + k2 + k3);
+            // kept flags as bytes, their running sums by one 24-bit multiply (byte i of run = kept among bytes 0..i,
+            // i < 3), and the three shift amounts 5 * run the same way (a shift only looks at its low 5 bits)
+            const uint32_t kept = (~skip80[j] >> 7) & 0x01010101u;
+            const uint32_t run = __umul24(kept, 0x010101u);
+            const uint32_t sh = __umul24(run, 5u);
+            pk[j] = (c & 0x1fu) | (((c >> 8) & 0x1fu) << (sh & 31u)) | (((c >> 16) & 0x1fu) << ((sh >> 8) & 31u)) |
+                    ((c >> 24) << ((sh >> 16) & 31u));
+            cnt[j] = (int)(((run >> 16) & 0xffu) + (kept >> 24));
         }
         const int sh1 = 5 * cnt[0], sh2 = sh1 + 5 * cnt[1], sh3 = sh2 + 5 * cnt[2];   // <= 20, 40, 60
         lo = (uint64_t)pk[0] | ((uint64_t)pk[1] << sh1) | ((uint64_t)pk[2] << sh2) | ((uint64_t)pk[3] << sh3);
