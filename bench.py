@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 is the bench line (BASELINE.json configs[1]); c3 / c5 reproduce the other shapes")
     ap.add_argument("--host-steps", type=int, default=3, help="timed host-to-host steps (0: skip that leg)")
+    ap.add_argument("--onehot-lines", type=int, default=16384, help="lines of the -s reader leg (0: skip it)")
     args = ap.parse_args()
     if args.reads == 1_000_000 and args.db_scale == 1.0 and args.workload == "c2":
         TRAFFIC.update(_load_traffic())
@@ -192,6 +193,39 @@ def main():
                     "how": "stag_classify_a2m on page-locked host buffers (stag_host_alloc): sub-batches of 65,536 reads, "
                            "text up / kernels / results down on three streams"}
         del h_text, h_offs, h_out
+
+    # ---- the -s reader (classify.py:16-20) on the GPU, measured: a file of one-hot lines (what -S writes: 2 bytes
+    # per feature) -> lines found on the host -> fields parsed by k_parse_onehot -> walk -> host results
+    onehot_leg = None
+    if args.onehot_lines > 0 and world == 1:
+        import tempfile
+        from stag_amd import ingest
+        from stag_amd.classify import parse_onehot_line
+        m = min(args.onehot_lines, n)
+        sub_text = np.concatenate([text[:int(offs[m])], np.zeros(-int(offs[m]) % 16, dtype=np.uint8)])
+        rows = db.classify_a2m_text(sub_text, offs[:m + 1], want_bits=True).bits
+        with tempfile.NamedTemporaryFile(suffix=".tsv", delete=False) as fh:
+            fh.write(ingest.format_onehot(["read%d" % i for i in range(m)], rows, wl.tables.n_features))
+            tsv = fh.name
+        size = os.path.getsize(tsv)
+
+        def onehot_pass():
+            got = []
+            for ids, tx, bb, be, raw in ingest.onehot_text_batches(tsv, slow_line=parse_onehot_line):
+                got.append(db.classify_onehot_text(tx, bb, be, parse_onehot_line, raw)[0])
+            return got
+
+        onehot_pass()
+        o0 = time.perf_counter()
+        got = onehot_pass()
+        odt = time.perf_counter() - o0
+        os.remove(tsv)
+        same = all(np.array_equal(np.concatenate([getattr(g, f) for g in got]), out[f][:m].cpu().numpy())
+                   for f in ("path_node", "path_prob", "selected", "n_aligned", "status"))
+        onehot_leg = {"value": round(m / odt, 1), "unit": "seqs/s", "lines": m, "file_bytes": int(size),
+                      "text_GBs": round(size / odt / 1e9, 2), "equals_device_resident_results": bool(same),
+                      "how": "ingest.onehot_text_batches (stag_onehot_lines on one core, page-locked chunks) + "
+                             "Database.classify_onehot_text (k_parse_onehot + the walk); file in the page cache"}
 
     if rank != 0:
         if world > 1:
@@ -328,7 +362,7 @@ def main():
                    "reads_per_gpu": n, "ncol": ncol, "L": t.n_features, "depth": D, "n_nodes": t.n_nodes,
                    "nnz_coefficients": t.nnz, "table_bytes": db.table_bytes, "classified_ok": n_ok,
                    "sharding": "reads split across ranks, tables replicated, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_c, "host_to_host": host_leg,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_c, "host_to_host": host_leg, "onehot_text": onehot_leg,
         "parity": parity,
     }))
     if world > 1:

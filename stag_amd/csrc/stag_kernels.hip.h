@@ -147,7 +147,7 @@ constexpr KeepLut make_keep_lut() {
             }
     return t;
 }
-__device__ __attribute__((aligned(16))) const KeepLut KEEP_LUT = make_keep_lut();
+__device__ const KeepLut KEEP_LUT = make_keep_lut();
 
 // Reductions inside each record's group of G lanes with DPP moves; the result is valid in the
 // group's LAST lane (gl == G - 1).
@@ -235,15 +235,13 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     // the vector's bytes that belong to the record: [lo_cut, hi_cut) of 16 (all ones except in a record's first and
     // last vector).
     constexpr int VPL = 2, STEP = 16 * VPL * G;  // bytes of a record per step
-    // where the record's last 16-byte vector starts, relative to the record's first byte (a multiple of 16 from
-    // -lead).  src = the address of relative position 0; an empty record has nothing in the buffer that is safe to
-    // read (it may sit at the buffer's very end): its lanes fetch 16 bytes of a constant instead.
-    const int last_rel = ((max(len, 1) - 1 + lead) & ~15) - lead;
-    const uint8_t *const src = len > 0 ? text + begin : reinterpret_cast<const uint8_t *>(KEEP_LUT.m) + lead;
+    // A vector is fetched only if it starts before the record's end: the same bytes, no others, that every
+    // earlier form of this kernel has read (positions relative to the record's first byte; rel is a multiple of 16
+    // from -lead, so the address is 16-byte aligned).
+    const uint8_t *const src = text + begin;
     auto load16 = [&](int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
-        // a vector past the record's end is fetched from the record's last vector instead (no branch, no
-        // zero-fill; its keep mask is all zero, so what it holds does not matter)
-        const uint4 v = *reinterpret_cast<const uint4 *>(src + min(rel, last_rel));
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (rel < len) v = *reinterpret_cast<const uint4 *>(src + rel);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         uint4 q = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         if (rel < 0 || rel + 16 > len) {     // the record's first / last vector, or one past its end
