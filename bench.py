@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
                     help="c2 is the bench line (BASELINE.json configs[1]); c3 / c5 reproduce the other shapes")
     ap.add_argument("--host-steps", type=int, default=3, help="timed host-to-host steps (0: skip that leg)")
-    ap.add_argument("--onehot-lines", type=int, default=16384, help="lines of the -s reader leg (0: skip it)")
+    ap.add_argument("--onehot-lines", type=int, default=65536, help="lines of the -s reader leg (0: skip it)")
     args = ap.parse_args()
     if args.reads == 1_000_000 and args.db_scale == 1.0 and args.workload == "c2":
         TRAFFIC.update(_load_traffic())
