@@ -592,3 +592,23 @@ def test_protein_and_gene_streams_are_paired_record_by_record(engine, monkeypatc
 def ingest_batches(fh):
     from stag_amd import ingest
     return ingest.fasta_batches(fh, batch_records=5, text_mode=True)
+
+
+def test_long_rows_of_a_batch_equal_the_per_row_formatter():
+    """Database.result_rows formats the long fields of a whole batch in one pass (every float through repr once, the
+    lineage strings once per end node); result_row is the per-row statement of classify.py:116-122.  Same rows,
+    also with filtered sequences in between and with paths of different lengths."""
+    import bench_workload as bw
+    from fake_engine import OracleDatabase
+    from stag_amd import _lib
+    from stag_amd.tables import pack_bool_rows
+    wl = bw.make_db(11, 40, [3, 9, 27, 50], 0.1, name="t")
+    db = OracleDatabase(wl.tables)
+    rng = np.random.default_rng(1)
+    X = rng.random((3000, wl.tables.n_features)) < 0.2
+    res = db.classify_bits(pack_bool_rows(X, db.words_per_row))
+    res.status[::97] = _lib.SEQ_FILTERED
+    ids = ["r%d" % i for i in range(len(X))]
+    want = [db.result_row(res, i, ids[i], True) for i in range(res.n) if res.status[i] == _lib.SEQ_OK]
+    assert db.result_rows(res, ids, True) == want and len(want) > 2900
+    assert db.result_rows(res, ids, False) == [w[:2] for w in want]
