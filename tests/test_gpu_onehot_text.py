@@ -192,3 +192,25 @@ def test_parse_then_classify_protocol_is_checked():
         rc = _lib.lib().stag_onehot_text_parse(db.handle, _lib.ptr(text), len(text), _lib.ptr(bb), _lib.ptr(be), 1,
                                                _lib.ptr(res), _lib.ptr(res))
         assert rc != 0 and "not inside the text buffer" in _lib.lib().stag_last_error().decode()
+
+
+def test_device_parser_on_genome_wide_lines(tmp_path):
+    """Lines of the concatenated genome database's width (L = 157,500: 315 kB per line, 77 steps of a wave), one of them
+    damaged in its last field, one a field short: rows, counts and flags as the per-line parser gives them."""
+    L = 157_500
+    W = words_per_row(L)
+    rng = np.random.default_rng(21)
+    X = rng.random((6, L)) < 0.3
+    blob = ingest.format_onehot(["g%d" % i for i in range(6)], pack_bool_rows(X, W), L)
+    lines = blob.split(b"\n")[:-1]
+    lines[2] = lines[2][:-1] + b"5"          # int("5") is True for the reference: the slow path sets that bit
+    lines[4] = lines[4][:-2]                 # one field short
+    path = tmp_path / "wide.tsv"
+    path.write_bytes(b"\n".join(lines) + b"\n")
+    got = device_rows(str(path), L, 1 << 22, 4)
+    assert [g[0] for g in got] == ["g%d" % i for i in range(6)]
+    assert [g[1] for g in got] == [L, L, L, L, L - 1, L]
+    X[2, -1] = True
+    for i in (0, 1, 2, 3, 5):
+        assert got[i][2] == X[i].astype(int).tolist(), i
+    assert got[4][2] is None
