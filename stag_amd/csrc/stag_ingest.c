@@ -23,6 +23,7 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
     int64_t n = 0, pos = 0, used = text_used_in;
     offs[0] = used;
     *consumed = 0;
+    if (max_records == 0) { *text_used = used; return 0; }   /* no room for a record: nothing is consumed */
     /* the open record */
     int open = 0, fb = 0;
     int64_t r_begin = 0, r_id = 0, r_idlen = -1, r_lines = 0, r_text = used;

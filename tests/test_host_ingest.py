@@ -305,3 +305,25 @@ def test_onehot_line_finder_random_files(tmp_path):
             for gid, body, line in got:
                 if body:
                     assert body == "\t".join(line.rstrip().split("\t")[1:]), (case, data)
+
+
+def test_parsers_are_memory_safe_under_address_and_ub_sanitizers(tmp_path):
+    """tests/csrc/sanitize_ingest.c drives the four entry points of libstag_ingest with random and well-formed text in
+    exactly sized heap blocks, chunked as the Python batchers chunk it; built with -fsanitize=address,undefined, any
+    read or write outside a buffer aborts the run."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "sanitize_ingest")
+    build = subprocess.run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-static-libasan",
+                            "-I", os.path.join(root, "include"), "-o", exe,
+                            os.path.join(root, "tests", "csrc", "sanitize_ingest.c"),
+                            os.path.join(root, "stag_amd", "csrc", "stag_ingest.c")], capture_output=True, text=True)
+    if build.returncode != 0:
+        pytest.skip("sanitizer build not available: " + build.stderr[-300:])
+    run = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert run.stdout.strip() == "ok 1500"
