@@ -293,18 +293,29 @@ class Database:
         raises the reference's exception for the first failing sequence."""
         raise_for_status(res.status, ids)
         ok = np.flatnonzero(res.status == _lib.SEQ_OK).tolist()
+        D, K = res.path_prob.shape[1], len(self.keys)
+        path_len, sel_all = res.path_len.tolist(), res.selected.tolist()
+        last = np.maximum(res.path_len.astype(np.int64) - 1, 0)
+        end_all = res.path_node[np.arange(res.n), last].tolist() if D else [-1] * res.n
         if not long_out:
-            return [self.result_row(res, i, ids[i], False) for i in ok]
+            assigned = {}     # (end position, selected) -> the assigned lineage: a position fixes its path
+            rows = []
+            for i in ok:
+                sel = sel_all[i]
+                key = (end_all[i] if path_len[i] else -1, sel)
+                text = assigned.get(key)
+                if text is None:
+                    selected = self.keys[sel] if sel >= 0 else -1
+                    text = assigned[key] = ";".join(self.lineage(res, i)[0:int(selected) + 1])
+                rows.append([ids[i], text])
+            return rows
         # the long fields of a whole batch: every float goes through repr() in one pass over flat lists (the same
         # strings as result_row's repr(float(p)); a row then only slices and joins)
-        D, K = res.path_prob.shape[1], len(self.keys)
         perc_all = list(map(repr, res.path_prob.ravel().tolist()))
         level_all = list(map(repr, res.level_prob[:, :K].ravel().tolist()))
         prefix = [k + ":" for k in self.keys]
         n_aligned = list(map(str, res.n_aligned.tolist()))
-        path_len, lead_all, sel_all = res.path_len.tolist(), res.n_lead_single.tolist(), res.selected.tolist()
-        last = np.maximum(res.path_len.astype(np.int64) - 1, 0)
-        end_all = res.path_node[np.arange(res.n), last].tolist() if D else [-1] * res.n
+        lead_all = res.n_lead_single.tolist()
         rows = []
         joined = {}       # (end position, selected) -> the two lineage strings: a position fixes its path
         for i in ok:
