@@ -224,7 +224,7 @@ def main():
                    for f in ("path_node", "path_prob", "selected", "n_aligned", "status"))
         onehot_leg = {"value": round(m / odt, 1), "unit": "seqs/s", "lines": m, "file_bytes": int(size),
                       "text_GBs": round(size / odt / 1e9, 2), "equals_device_resident_results": bool(same),
-                      "how": "ingest.onehot_text_batches (stag_onehot_lines on one core, page-locked chunks) + "
+                      "how": "ingest.onehot_text_batches (file read by a thread into page-locked 32 MB chunks, stag_onehot_lines on one core) + "
                              "Database.classify_onehot_text (k_parse_onehot + the walk); file in the page cache"}
 
     if rank != 0:

@@ -16,6 +16,9 @@ way the reference does (Python str methods), so the output is the reference's in
 import ctypes
 import io
 import os
+import queue
+import stat
+import threading
 
 import numpy as np
 
@@ -240,38 +243,118 @@ def onehot_batches(path, n_features, words_per_row, batch_rows=1 << 14, chunk_by
 
 
 class _PinnedRing:
-    """Page-locked byte buffers used in turn (pageable arrays when the GPU library cannot give such memory)."""
+    """Page-locked byte buffers used in turn, allocated when first used (pageable arrays when the GPU library cannot
+    give such memory)."""
 
     def __init__(self, slots, nbytes):
-        self.bufs, self.turn = [], 0
-        for _ in range(max(slots, 2)):
-            try:
-                from . import _lib
-                keep = _lib.PinnedArray(nbytes, np.uint8)
-                self.bufs.append((keep, keep.a))
-            except Exception:
-                self.bufs.append((None, np.empty(nbytes, dtype=np.uint8)))
+        self.bufs, self.turn, self.nbytes = [None] * max(slots, 2), 0, nbytes
 
     def next(self):
         self.turn = (self.turn + 1) % len(self.bufs)
+        if self.bufs[self.turn] is None:
+            try:
+                from . import _lib
+                keep = _lib.PinnedArray(self.nbytes, np.uint8)
+                self.bufs[self.turn] = (keep, keep.a)
+            except Exception:
+                self.bufs[self.turn] = (None, np.empty(self.nbytes, dtype=np.uint8))
         return self.bufs[self.turn][1]
 
 
-def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 27, ring_slots=3, slow_line=None):
+def _last_line_end(buf, have):
+    """End (exclusive) of the last complete line of buf[:have] for a reader with universal newlines that may get
+    more bytes: after the last '\n'; without any, after the last '\r' that is not the last byte (a '\n' could
+    still follow that one).  0: no complete line."""
+    for byte, limit in ((10, have), (13, have - 1)):
+        hi, span = limit, 1 << 16
+        while hi > 0:
+            lo = max(0, hi - span)
+            hit = np.flatnonzero(buf[lo:hi] == byte)
+            if len(hit):
+                return lo + int(hit[-1]) + 1
+            hi, span = lo, span * 8
+    return 0
+
+
+class _LineChunks:
+    """Reads a file in a thread of its own, one buffer of the ring ahead of the consumer: iterating yields
+    (buf, have) with buf[:have] = whole lines only (the bytes after the last line end of a read open the next
+    buffer).  File reads release the GIL, so they run beside the consumer's line finding, its GPU calls and its
+    formatting."""
+
+    def __init__(self, path, ring, cap):
+        self.path, self.ring, self.cap = path, ring, cap
+        self.q = queue.Queue(maxsize=1)
+        self.stop = threading.Event()
+        self.thread = threading.Thread(target=self._run, name="stag-onehot-reader", daemon=True)
+        self.thread.start()
+
+    def _put(self, item):
+        while not self.stop.is_set():
+            try:
+                self.q.put(item, timeout=0.1)
+                return
+            except queue.Full:
+                pass
+
+    def _run(self):
+        try:
+            room = self.cap - 16          # (16 bytes stay free: the GPU's copy of a batch is padded)
+            with open(self.path, "rb", buffering=0) as fh:
+                tail, ended = b"", False
+                while not ended and not self.stop.is_set():
+                    buf = self.ring.next()
+                    rest = len(tail)
+                    buf[:rest] = np.frombuffer(tail, dtype=np.uint8)
+                    have, ended = _fill(fh, buf[:room], rest)
+                    cut = have if ended else _last_line_end(buf, have)
+                    if cut == 0 and not ended:
+                        raise ValueError("a line of %s is longer than the read buffer (%d bytes)" % (self.path, self.cap))
+                    tail = buf[cut:have].tobytes()
+                    self._put((buf, cut))
+            self._put(None)
+        except BaseException as e:      # noqa: BLE001  (handed to the consumer, which raises it)
+            self._put(e)
+
+    def __iter__(self):
+        while True:
+            item = self.q.get()
+            if item is None:
+                return
+            if isinstance(item, BaseException):
+                raise item
+            yield item
+
+    def close(self):
+        self.stop.set()
+        while True:                      # a producer blocked in put() sees the flag; one waiting in read() ends with it
+            try:
+                self.q.get_nowait()
+            except queue.Empty:
+                break
+        self.thread.join(timeout=5.0)
+
+
+def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 25, ring_slots=3, slow_line=None):
     """Yields (ids, text, body_begin, body_end, raw) for the lines of a -s file WITHOUT parsing their fields:
     text is a uint8 view (of a page-locked buffer, valid until ring_slots - 1 further batches have been produced)
     that holds whole lines, line i's fields are text[body_begin[i]:body_end[i]] (see stag_onehot_lines), and
     raw(i) returns line i as the str the reference would iterate over (for the slow path).  A batch is the whole
     lines of one chunk of the file, at most batch_rows of them.  slow_line(str) -> (id, bool array) names the
-    lines the line finder flags (they end in a non-ASCII byte, which may be white space for str.rstrip)."""
+    lines the line finder flags (they end in a non-ASCII byte, which may be white space for str.rstrip).
+    The file is read by a thread of its own, one chunk ahead (two buffers more than ring_slots); chunks of 32 MB keep
+    the page-locked memory (and the time it takes to lock it, which a short file would notice) small."""
     L = lib()
     cap = max(int(chunk_bytes), 64)
-    ring = _PinnedRing(ring_slots, cap)
-    with open(path, "rb") as fh:
-        buf, have, ended = ring.next(), 0, False
-        while True:
-            if not ended:
-                have, ended = _fill(fh, buf[:cap - 16], have)     # (16 bytes stay free: the GPU's copy is padded)
+    try:                                  # a small regular file needs no full-size buffers
+        st = os.stat(path)
+        if stat.S_ISREG(st.st_mode):
+            cap = min(cap, max(st.st_size + 64, 1 << 16))
+    except OSError:
+        pass
+    chunks = _LineChunks(path, _PinnedRing(ring_slots + 2, cap), cap)
+    try:
+        for buf, have in chunks:
             pos = 0
             while pos < have:
                 recs = np.zeros(batch_rows, dtype=RECORD)
@@ -279,12 +362,11 @@ def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 27, ring_slot
                 be = np.zeros(batch_rows, dtype=np.int64)
                 consumed = ctypes.c_int64(0)
                 view = buf[pos:have]
-                n = L.stag_onehot_lines(_ptr(view), len(view), int(ended), batch_rows, _ptr(recs), _ptr(bb), _ptr(be),
+                # final: the chunk ends at a line end (or at the end of the file), nothing is left over
+                n = L.stag_onehot_lines(_ptr(view), len(view), 1, batch_rows, _ptr(recs), _ptr(bb), _ptr(be),
                                         ctypes.byref(consumed))
-                if n < 0:
+                if n <= 0 or consumed.value <= 0:
                     raise ValueError("stag_onehot_lines: bad arguments")
-                if n == 0:
-                    break             # the rest of the buffer is an incomplete line
                 recs = recs[:n]
                 text = view[:consumed.value]
                 mv = memoryview(text)
@@ -299,16 +381,8 @@ def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 27, ring_slot
                     ids[i] = slow_line(raw(int(i)))[0]
                 yield ids, text, bb[:n], be[:n], raw
                 pos += consumed.value
-            rest = have - pos
-            if ended:
-                if rest:
-                    raise ValueError("unparsed bytes at the end of %s" % path)    # (the line finder takes everything)
-                return
-            if pos == 0 and have >= cap - 16:
-                raise ValueError("a line of %s is longer than the read buffer (%d bytes)" % (path, cap))
-            nxt = ring.next()         # the incomplete line moves to the front of the next buffer
-            nxt[:rest] = buf[pos:have]
-            buf, have = nxt, rest
+    finally:
+        chunks.close()
 
 
 def format_onehot(ids, bits, n_features):

@@ -327,3 +327,27 @@ def test_parsers_are_memory_safe_under_address_and_ub_sanitizers(tmp_path):
     run = subprocess.run([exe, "1500"], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr[-2000:]
     assert run.stdout.strip() == "ok 1500"
+
+
+def test_onehot_line_finder_reader_thread(tmp_path):
+    """The file is read one chunk ahead by a thread: lone-'\\r' line ends (no '\\n' to cut a chunk at), a last line
+    without line end, an empty file; a generator that is dropped early ends its reader."""
+    import threading
+    path = tmp_path / "r.tsv"
+    body = "\t".join("01"[i % 2] for i in range(9))
+    for sep, last in (("\r", "\r"), ("\r", ""), ("\n", ""), ("\r\n", "\r\n")):
+        lines = ["id%d\t%s" % (i, body) for i in range(50)]
+        path.write_bytes((sep.join(lines) + last).encode())
+        for chunk in (64, 100, 1 << 12):
+            got = lines_of(str(path), chunk, batch_rows=3)
+            assert [g[0] for g in got] == ["id%d" % i for i in range(50)], (sep, last, chunk)
+            assert all(g[1] == body for g in got)
+    path.write_bytes(b"")
+    assert lines_of(str(path), 64) == []
+    path.write_bytes(("\n".join("id%d\t%s" % (i, body) for i in range(5000)) + "\n").encode())
+    before = threading.active_count()
+    gen = ingest.onehot_text_batches(str(path), batch_rows=2, chunk_bytes=256, slow_line=parse_onehot_line)
+    assert next(gen)[0] == ["id0", "id1"]
+    assert threading.active_count() == before + 1
+    gen.close()
+    assert threading.active_count() == before
