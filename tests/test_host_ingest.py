@@ -351,3 +351,16 @@ def test_onehot_line_finder_reader_thread(tmp_path):
     assert threading.active_count() == before + 1
     gen.close()
     assert threading.active_count() == before
+
+
+def test_onehot_line_finder_lines_far_longer_than_the_search_window(tmp_path):
+    """The reader looks for a chunk's last line end in windows that grow backwards from the chunk's end (64 kB first):
+    lines of 300 kB in 1 MB chunks."""
+    nf = 150_000
+    body = "\t".join("01"[(i * 7) % 2] for i in range(nf))
+    path = tmp_path / "wide.tsv"
+    path.write_bytes("".join("g%d\t%s\n" % (i, body) for i in range(9)).encode())
+    got = lines_of(str(path), 1 << 20, batch_rows=2)
+    assert [g[0] for g in got] == ["g%d" % i for i in range(9)] and all(g[1] == body for g in got)
+    with pytest.raises(ValueError):
+        lines_of(str(path), 1 << 18)
