@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <new>
 #include <string>
@@ -39,20 +40,101 @@ int fail(int code, const char *fmt, ...) {
                         hipGetErrorString(e_), __FILE__, __LINE__);                           \
     } while (0)
 
+// ---- the bounds-checked build (see stag_kernels.hip.h): the table of device allocations the kernels may touch.
+// Persistent entries are the library's own buffers (DevBuf registers them), temporary ones the buffers of the
+// call at hand (each launching helper names what its kernels are given).  Every launch of such a build is
+// followed by a device synchronisation and a look at g_violation (launch_check), so the table only changes while
+// nothing runs.  Fresh buffers are filled with 0xff, so that a read of memory nobody wrote shows up the same way
+// on every run.  In the product build all of this is empty.
+#ifdef STAG_CHECKED
+struct CheckRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> persistent;
+    std::vector<std::pair<uintptr_t, size_t>> temp;
+    bool dirty = true;
+} g_chk;
+void chk_register(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_chk.mu);
+    g_chk.persistent[(uintptr_t)p] = bytes;
+    g_chk.dirty = true;
+}
+void chk_unregister(const void *p) {
+    std::lock_guard<std::mutex> lock(g_chk.mu);
+    g_chk.persistent.erase((uintptr_t)p);
+    g_chk.dirty = true;
+}
+void chk_temp_clear() {
+    std::lock_guard<std::mutex> lock(g_chk.mu);
+    g_chk.temp.clear();
+    g_chk.dirty = true;
+}
+void chk_temp(const void *p, size_t bytes) {
+    if (!p || !bytes) return;
+    std::lock_guard<std::mutex> lock(g_chk.mu);
+    g_chk.temp.emplace_back((uintptr_t)p, bytes);
+    g_chk.dirty = true;
+}
+int chk_upload() {   // the current device's copy of the table (cheap enough to send before every launch)
+    static CheckTable t;
+    std::lock_guard<std::mutex> lock(g_chk.mu);
+    t.n = 0;
+    auto add = [&](uintptr_t a, size_t b) {
+        if (t.n < (uint32_t)CHECK_MAX) { t.lo[t.n] = a; t.hi[t.n] = a + b; }
+        ++t.n;
+    };
+    for (auto &e : g_chk.persistent) add(e.first, e.second);
+    for (auto &e : g_chk.temp) add(e.first, e.second);
+    if (t.n > (uint32_t)CHECK_MAX) return fail(STAG_E_INVALID, "checked build: %u allocations, the table holds %d", t.n, CHECK_MAX);
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_check), &t, sizeof t));
+    return STAG_OK;
+}
+int chk_collect(const char *what) {
+    unsigned long long v[4] = {0, 0, 0, 0};
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(v, HIP_SYMBOL(g_violation), sizeof v));
+    if (!v[0]) return STAG_OK;
+    const unsigned long long zero[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_violation), zero, sizeof zero));
+    const long long line = (long long)v[1];
+    if (line < 0)
+        return fail(STAG_E_INVALID, "checked build: %s: %llu violations, the first a failed condition at stag_kernels.hip.h:%lld (values %llu, %llu)",
+                    what, v[0], -line, v[2], v[3]);
+    return fail(STAG_E_INVALID, "checked build: %s: %llu accesses outside every known allocation, the first at stag_kernels.hip.h:%lld, address %#llx (%llu bytes)",
+                what, v[0], line, v[2], v[3]);
+}
+#define CHK_TEMP_CLEAR() chk_temp_clear()
+#define CHK_TEMP(p, bytes) chk_temp((p), (size_t)(bytes))
+#define CHK_UPLOAD()                         \
+    do {                                     \
+        const int rc_ = chk_upload();        \
+        if (rc_) return rc_;                 \
+    } while (0)
+#else
+#define CHK_TEMP_CLEAR() do { } while (0)
+#define CHK_TEMP(p, bytes) do { } while (0)
+#define CHK_UPLOAD() do { } while (0)
+#endif
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;  // elements
     int reserve(size_t n) {
         if (n <= cap) return STAG_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
+        release();
         HIP_TRY(hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)));
         cap = n;
+#ifdef STAG_CHECKED
+        chk_register(p, std::max<size_t>(n, 1) * sizeof(T));
+        HIP_TRY(hipMemset(p, 0xff, std::max<size_t>(n, 1) * sizeof(T)));
+#endif
         return STAG_OK;
     }
     void release() {
+#ifdef STAG_CHECKED
+        if (p) chk_unregister(p);
+#endif
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
@@ -100,10 +182,44 @@ int scratch_of(int device, unsigned char **out) {
         HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
         if (!p) return fail(STAG_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
         g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+#ifdef STAG_CHECKED
+        chk_register(p, STAG_NOALLOC_SCRATCH_BYTES);
+#endif
     }
     *out = g_scratch_ptr[device];
     return STAG_OK;
 }
+
+// Streams and events of the host pipeline (stag_classify_a2m) come from a per-device pool and go back to it when
+// their handle is destroyed; the pool never destroys them.  A HIP stream owns (a share of) a hardware queue, and
+// the runtime creates and destroys that queue with the first / last stream that uses it: a process that opens
+// and closes many handles (the differential fuzz: thousands) would otherwise create and destroy hardware queues
+// thousands of times, which is what the GPU faults of that tool coincided with.
+struct PipePool {
+    std::mutex mu;
+    std::vector<hipStream_t> streams[MAX_DEVICES];
+    std::vector<hipEvent_t> events[MAX_DEVICES];
+    hipError_t stream(int device, hipStream_t *out) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto &v = streams[device];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+    }
+    hipError_t event(int device, hipEvent_t *out) {
+        std::lock_guard<std::mutex> lock(mu);
+        auto &v = events[device];
+        if (!v.empty()) { *out = v.back(); v.pop_back(); return hipSuccess; }
+        return hipEventCreateWithFlags(out, hipEventDisableTiming);
+    }
+    void give_back(int device, hipStream_t st) {   // st is idle
+        std::lock_guard<std::mutex> lock(mu);
+        streams[device].push_back(st);
+    }
+    void give_back(int device, hipEvent_t ev) {
+        std::lock_guard<std::mutex> lock(mu);
+        events[device].push_back(ev);
+    }
+} g_pipe_pool;
 }  // namespace
 
 struct stag_db {
@@ -179,10 +295,10 @@ struct stag_db {
             sl.selected.release(); sl.n_aligned.release(); sl.status.release(); sl.n_char.release();
             sl.path_prob.release(); sl.level_prob.release(); sl.bits.release();
             for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down})
-                if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+                if (*e) { g_pipe_pool.give_back(device, *e); *e = nullptr; }
         }
         for (hipStream_t *st : {&s_up, &s_run, &s_down})
-            if (*st) { (void)hipStreamDestroy(*st); *st = nullptr; }
+            if (*st) { (void)hipStreamSynchronize(*st); g_pipe_pool.give_back(device, *st); *st = nullptr; }
     }
 };
 
@@ -219,10 +335,36 @@ int check_device(int device) {
     return STAG_OK;
 }
 
+// STAG_TRACE_FILE=<path>: every kernel launch is announced in that file (flushed) after the stream's earlier work
+// has been waited for, so that after a GPU fault the file's last line names the kernel that was running.
+// A debugging aid (it serialises host and device); unset, it costs one branch per launch.
+FILE *g_trace = nullptr;
+bool g_trace_init = false;
+void trace_launch(hipStream_t st, const char *fmt, ...) {
+    if (!g_trace_init) {
+        g_trace_init = true;
+        const char *path = getenv("STAG_TRACE_FILE");
+        if (path && *path) g_trace = fopen(path, "a");
+    }
+    if (!g_trace) return;
+    const hipError_t e = hipStreamSynchronize(st);
+    fprintf(g_trace, "  earlier work: %s\n", e == hipSuccess ? "done" : hipGetErrorString(e));
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(g_trace, fmt, ap);
+    va_end(ap);
+    fputc('\n', g_trace);
+    fflush(g_trace);
+}
+
 int launch_check(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(STAG_E_HIP, "launch of %s failed: %s", what, hipGetErrorString(e));
+#ifdef STAG_CHECKED
+    return chk_collect(what);
+#else
     return STAG_OK;
+#endif
 }
 
 int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
@@ -231,10 +373,19 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
                bool full_rows = true) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
+    // (a kernel handed a null output would write to address 0: a GPU memory fault, not an error code)
+    if (!d_text || !d_offs || !d_bits || !d_n_char || !d_n_aligned || !d_status)
+        return fail(STAG_E_INVALID, "encode: null buffer (text %p, offsets %p, rows %p, n_char %p, n_aligned %p, status %p)",
+                    (const void *)d_text, (const void *)d_offs, (void *)d_bits, (void *)d_n_char, (void *)d_n_aligned, (void *)d_status);
     if (((uintptr_t)d_text & 15) || ((uintptr_t)d_bits & 15))
         return fail(STAG_E_INVALID, "d_text and d_bits must be 16-byte aligned");
     if (text_bytes & 15)
         return fail(STAG_E_INVALID, "text_bytes (the size of the text buffer) must be a multiple of 16: pad the buffer");
+    CHK_TEMP_CLEAR();
+    CHK_TEMP(d_text, text_bytes); CHK_TEMP(d_offs, (n + (d_ends ? 0 : 1)) * 8); CHK_TEMP(d_ends, n * 8);
+    CHK_TEMP(d_bits, (size_t)n * W * 4); CHK_TEMP(d_n_char, n * 4); CHK_TEMP(d_n_aligned, n * 4); CHK_TEMP(d_status, n * 4);
+    CHK_TEMP(d_win, n * 4); CHK_TEMP(d_pre_status, n * 4);
+    CHK_UPLOAD();
     // lanes per record: the candidate that wastes the fewest lane slots on an average record
     // (ties go to the wider group: fewer, longer-lived rows in LDS)
     const int64_t avg = std::max<int64_t>(1, text_bytes / n);
@@ -255,6 +406,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         Prof p(db_for_prof, st, 0);
+        trace_launch(st, "k_encode_a2m G=%d full=%d n=%lld L=%d W=%d text_bytes=%lld grid=%lld lds=%zu", G, (int)(full_rows || !d_win), (long long)n, L, W, (long long)text_bytes, (long long)grid, lds);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
                            d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win, d_ends, d_pre_status);
         return STAG_OK;
@@ -339,10 +491,22 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
     if (n == 0) return STAG_OK;
     if (n > 0x7fffffff - 1024) return fail(STAG_E_INVALID, "batch of %lld sequences is too large; split it", (long long)n);
     if ((uintptr_t)d_bits & 15) return fail(STAG_E_INVALID, "d_bits must be 16-byte aligned");
+    // (a null buffer handed to a kernel is a GPU memory fault, not an error code: refuse it here)
+    if (!d_bits || !wk.node || !wk.pos || !wk.count || !wk.task_off || !wk.n_tasks || !wk.order || !wk.lvl || !wk.tasks ||
+        !wk.win || !o.path_node || !o.path_prob || !o.path_len || !o.lead || !o.level_prob || !o.selected || !o.n_aligned ||
+        !o.status)
+        return fail(STAG_E_INVALID, "walk: a workspace or result buffer is null (the handle's workspace was not reserved)");
     const int D = std::max(db->max_depth, 1);
     const unsigned g256 = (unsigned)((n + 255) / 256);
+    CHK_TEMP_CLEAR();
+    CHK_TEMP(d_bits, (size_t)n * db->W * 4); CHK_TEMP(d_status_in, n * 4);
+    CHK_TEMP(o.path_node, (size_t)n * D * 4); CHK_TEMP(o.path_prob, (size_t)n * D * 8); CHK_TEMP(o.path_len, n * 4);
+    CHK_TEMP(o.lead, n * 4); CHK_TEMP(o.level_prob, (size_t)n * std::max(db->n_keys, 1) * 8); CHK_TEMP(o.selected, n * 4);
+    CHK_TEMP(o.n_aligned, n * 4); CHK_TEMP(o.status, n * 4);
+    CHK_UPLOAD();
     if (count_aligned) {
         Prof p(db, st, 4, wk.prof);
+        trace_launch(st, "k_count_aligned n=%lld L=%d W=%d", (long long)n, db->L, db->W);
         hipLaunchKernelGGL(k_count_aligned, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, d_bits, n, db->L, db->W,
                            o.n_aligned, wk.win);
     }
@@ -350,6 +514,7 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         Prof p(db, st, 2, wk.prof);
         HIP_TRY(hipMemsetAsync(wk.count, 0, sizeof(int32_t) * db->n_nodes, st));
         if (db->max_depth == 0)
+            trace_launch(st, "k_init_status n=%lld", (long long)n);
             hipLaunchKernelGGL(k_init_status, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status);
     }
     int rc;
@@ -363,10 +528,12 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         LevelRec *cur = wk.lvl + (size_t)d * n;
         if (d == 0) {
             Prof p(db, st, 2, wk.prof);
+            trace_launch(st, "k_root_level n=%lld", (long long)n);
             hipLaunchKernelGGL(k_root_level, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status, wk.win, cur,
                                db->child_first.p, db->node_err.p, wk.order, wk.tasks, wk.n_tasks, hints);
         } else {
             Prof p(db, st, 2, wk.prof);
+            trace_launch(st, "k_assign+k_scan_level+k_scatter d=%d n=%lld lo=%d hi=%d", d, (long long)n, lo, hi);
             hipLaunchKernelGGL(k_assign, dim3((unsigned)((n + ASSIGN_SPAN - 1) / ASSIGN_SPAN)), dim3(ASSIGN_THREADS), 0, st,
                                n, lo, hi, d ? cur - n : (const LevelRec *)nullptr, cur, d_status_in, o.status, wk.node,
                                wk.count, wk.pos);
@@ -394,10 +561,12 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
             m.pf_off = db->pf_off.p; m.pfeat = db->pfeat.p; m.dig = db->dig.p; m.dig_base = db->dig_base.p;
             m.dig_ld = db->dig_ld.p; m.qscale = db->qscale.p; m.mfma_ok = db->mfma_ok.p;
             Prof p(db, st, 1, wk.prof);
+            trace_launch(st, "k_walk_mfma d=%d grid=%lld W=%d NC=%d", d, (long long)max_tasks, db->W, db->nchunks);
             hipLaunchKernelGGL(k_walk_mfma, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a, m);
         }
         if (has_gather) {
             Prof p(db, st, 1, wk.prof);
+            trace_launch(st, "k_walk_level d=%d grid=%lld W=%d NC=%d", d, (long long)max_tasks, db->W, db->nchunks);
             hipLaunchKernelGGL(k_walk_level, dim3((unsigned)max_tasks), dim3(NW * 64), 0, st, a);
         }
         if ((rc = launch_check("k_walk_level"))) return rc;
@@ -408,6 +577,7 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
         if (lds > 160 * 1024) return fail(STAG_E_INVALID, "tree depth %d + %d rank-cut keys exceed the rank-cut kernel's LDS tile", D, db->n_keys);
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)k_rankcut, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        trace_launch(st, "k_rankcut n=%lld D=%d K=%d", (long long)n, D, db->n_keys);
         hipLaunchKernelGGL(k_rankcut, dim3(g256), dim3(256), lds, st, n, D, db->max_depth, db->n_keys, db->n_tf, db->tf.p,
                            wk.lvl, o.path_node, o.path_prob, o.path_len, o.lead, o.level_prob, o.selected, o.status);
     }
@@ -848,6 +1018,11 @@ int stag_parse_onehot_dev(int32_t n_features, const char *d_text, int64_t text_b
     if ((text_bytes & 3) || ((uintptr_t)d_text & 3))
         return fail(STAG_E_INVALID, "d_text must be 4-byte aligned and text_bytes (the size of the buffer) a multiple of 4: pad the buffer");
     if ((n + 3) / 4 > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    CHK_TEMP_CLEAR();
+    CHK_TEMP(d_text, text_bytes); CHK_TEMP(d_body_begin, n * 8); CHK_TEMP(d_body_end, n * 8);
+    CHK_TEMP(d_bits, (size_t)n * stag_words_per_row(n_features) * 4); CHK_TEMP(d_n_fields, n * 4); CHK_TEMP(d_flag, n * 4);
+    CHK_UPLOAD();
+    trace_launch((hipStream_t)stream, "k_parse_onehot n=%lld L=%d", (long long)n, n_features);
     hipLaunchKernelGGL(k_parse_onehot, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_text, text_bytes, d_body_begin, d_body_end, n, n_features,
                        stag_words_per_row(n_features), d_bits, d_n_fields, d_flag);
@@ -993,12 +1168,12 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
     // ---- sub-batches: cut at record boundaries, at most PIPE_RECORDS records / PIPE_BYTES bytes each
     const int64_t PIPE_RECORDS = pipe_records(), PIPE_BYTES = (int64_t)96 << 20;
     const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
-    if (!db->s_up) {
-        HIP_TRY(hipStreamCreateWithFlags(&db->s_up, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&db->s_run, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&db->s_down, hipStreamNonBlocking));
+    if (!db->slot[1].down) {   // (the last one taken: a handle whose set-up failed half way takes the rest)
+        for (hipStream_t *st : {&db->s_up, &db->s_run, &db->s_down})
+            if (!*st) HIP_TRY(g_pipe_pool.stream(db->device, st));
         for (auto &sl : db->slot)
-            for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down}) HIP_TRY(hipEventCreateWithFlags(e, hipEventDisableTiming));
+            for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down})
+                if (!*e) HIP_TRY(g_pipe_pool.event(db->device, e));
     }
     for (auto &sl : db->slot) sl.used = false;
     auto fin = [&](int code) {   // on any exit nothing of this call may still be in flight
@@ -1014,13 +1189,37 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
             return fin(fail(e_ == hipErrorOutOfMemory ? STAG_E_NOMEM : STAG_E_HIP, "%s: %s (%s:%d)", #expr, \
                             hipGetErrorString(e_), __FILE__, __LINE__));                                \
     } while (0)
-    int64_t b0 = 0, j = 0;
-    while (b0 < n) {
+    // the cuts first, so that everything is reserved ONCE, for the largest sub-batch, before any work is queued
+    // (growing a buffer frees it, and the previous sub-batch's kernels would still be using it)
+    std::vector<int64_t> cuts{0};
+    int64_t max_m = 0, max_span = 0;
+    while (cuts.back() < n) {
+        const int64_t b0 = cuts.back();
         int64_t b1 = std::min(n, b0 + PIPE_RECORDS);
         if (offs[b1] - offs[b0] > PIPE_BYTES) {   // long records: fewer of them (at least one)
             b1 = std::upper_bound(offs + b0 + 1, offs + b1 + 1, offs[b0] + PIPE_BYTES) - offs - 1;
             b1 = std::max(b1, b0 + 1);
         }
+        cuts.push_back(b1);
+        max_m = std::max(max_m, b1 - b0);
+        // the 16-byte aligned stretch of the host text that holds records b0 .. b1 - 1
+        max_span = std::max(max_span, (offs[b1] - (offs[b0] & ~(int64_t)15) + 15) / 16 * 16);
+    }
+    for (size_t q = 0; q < std::min<size_t>(2, cuts.size() - 1); ++q) {
+        stag_db::Slot &sl = db->slot[q];
+        if ((rc = sl.text.reserve(max_span + 16)) || (rc = sl.offs.reserve(max_m + 1)) || (rc = sl.path_node.reserve(max_m * D)) ||
+            (rc = sl.path_prob.reserve(max_m * D)) || (rc = sl.path_len.reserve(max_m)) || (rc = sl.lead.reserve(max_m)) ||
+            (rc = sl.level_prob.reserve(max_m * K)) || (rc = sl.selected.reserve(max_m)) || (rc = sl.n_aligned.reserve(max_m)) ||
+            (rc = sl.status.reserve(max_m)) || (rc = sl.n_char.reserve(max_m)) ||
+            (bits_out && (rc = sl.bits.reserve((size_t)max_m * db->W))))
+            return fin(rc);
+    }
+    // (at least one byte of text: a sub-batch made of empty records only still needs the encode buffers.  With
+    // a span of 0 they used to stay unallocated and the encode kernel wrote its status to address 0 -- the GPU
+    // fault of the differential fuzz, one configuration in a few thousand: one empty record as the whole batch)
+    if ((rc = stag_db_reserve(db, max_m, std::max<int64_t>(max_span, 1)))) return fin(rc);
+    for (size_t j = 0; j + 1 < cuts.size(); ++j) {
+        const int64_t b0 = cuts[j], b1 = cuts[j + 1];
         const int64_t m = b1 - b0;
         stag_db::Slot &sl = db->slot[j & 1];
         // the slot's previous sub-batch has left the device before its buffers are overwritten
@@ -1030,12 +1229,6 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         // offsets need no rebasing
         const int64_t a0 = offs[b0] & ~(int64_t)15, a1 = offs[b1];
         const int64_t span = (a1 - a0 + 15) / 16 * 16;
-        if ((rc = sl.text.reserve(span + 16)) || (rc = sl.offs.reserve(m + 1)) || (rc = sl.path_node.reserve(m * D)) ||
-            (rc = sl.path_prob.reserve(m * D)) || (rc = sl.path_len.reserve(m)) || (rc = sl.lead.reserve(m)) ||
-            (rc = sl.level_prob.reserve(m * K)) || (rc = sl.selected.reserve(m)) || (rc = sl.n_aligned.reserve(m)) ||
-            (rc = sl.status.reserve(m)) || (rc = sl.n_char.reserve(m)) || (bits_out && (rc = sl.bits.reserve((size_t)m * db->W))) ||
-            (rc = stag_db_reserve(db, m, span)))
-            return fin(rc);
         PIPE_TRY(hipMemcpyAsync(sl.text.p, text + a0, a1 - a0, hipMemcpyHostToDevice, db->s_up));
         PIPE_TRY(hipMemcpyAsync(sl.offs.p, offs + b0, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, db->s_up));
         PIPE_TRY(hipEventRecord(sl.up, db->s_up));
@@ -1072,8 +1265,6 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         PIPE_TRY(down(n_char_out, sl.n_char.p, 4));
         PIPE_TRY(hipEventRecord(sl.down, db->s_down));
         sl.used = true;
-        b0 = b1;
-        ++j;
     }
 #undef PIPE_TRY
     hipError_t e = hipStreamSynchronize(db->s_down);
@@ -1122,6 +1313,9 @@ int stag_classify_concat(stag_db_t *db, int32_t n_genes, const int32_t *gene_len
          hipMemcpy(d_itab.p + n_genes, src_row, (size_t)n_genomes * n_genes * 4, hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) return done(fail(STAG_E_HIP, "host to device copy failed"));
     if (n_genomes > 0x7fffffff || (db->W + 255) / 256 > 65535) return done(fail(STAG_E_INVALID, "batch too large"));
+    CHK_TEMP_CLEAR();
+    CHK_UPLOAD();
+    trace_launch(nullptr, "k_concat_bits n=%lld", (long long)n_genomes);
     hipLaunchKernelGGL(k_concat_bits, dim3((unsigned)n_genomes, (unsigned)((db->W + 255) / 256)), dim3(256), 0, nullptr, n_genomes,
                        n_genes, d_tab.p, d_tab.p + n_genes + 1, d_itab.p, d_itab.p + n_genes, arena.p, db->bits.p, db->W);
     if ((rc = launch_check("k_concat_bits"))) return done(rc);
@@ -1141,6 +1335,18 @@ int stag_backtranslate_dev(const char *d_prot, int64_t prot_bytes, const int64_t
     if (out_bytes < 3 * prot_bytes) return fail(STAG_E_INVALID, "d_out must hold 3 * prot_bytes = %lld bytes", (long long)(3 * prot_bytes));
     if (n == 0) return STAG_OK;
     if ((n + 3) / 4 > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+    CHK_TEMP_CLEAR();
+    CHK_TEMP(d_prot, prot_bytes); CHK_TEMP(d_prot_offs, (n + 1) * 8); CHK_TEMP(d_gene_offs, (n + 1) * 8);
+    CHK_TEMP(d_out, out_bytes); CHK_TEMP(d_out_begin, n * 8); CHK_TEMP(d_out_end, n * 8); CHK_TEMP(d_status, n * 4);
+#ifdef STAG_CHECKED
+    {   // the gene text has no size argument: it ends where the last gene does
+        int64_t gene_bytes = 0;
+        HIP_TRY(hipMemcpy(&gene_bytes, d_gene_offs + n, sizeof gene_bytes, hipMemcpyDeviceToHost));
+        CHK_TEMP(d_gene, gene_bytes);
+    }
+#endif
+    CHK_UPLOAD();
+    trace_launch((hipStream_t)stream, "k_backtranslate n=%lld prot_bytes=%lld", (long long)n, (long long)prot_bytes);
     hipLaunchKernelGGL(k_backtranslate, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t *)d_prot, d_prot_offs, (const uint8_t *)d_gene, d_gene_offs, n, (int)check_length,
                        (uint8_t *)d_out, d_out_begin, d_out_end, d_status);

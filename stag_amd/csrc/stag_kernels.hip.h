@@ -20,6 +20,70 @@
 
 namespace stagk {
 
+// ------------------------------------------------------------------------------------------
+// Bounds-checked build (-DSTAG_CHECKED; `make checked` -> lib/libstag_hip_checked.so, selected at run time with
+// STAG_HIP_LIB).  Every global-memory access of the kernels is written with the macros below.  In the product
+// build they are the plain access (RDC: through the constant address space, see as_const).  In the checked build
+// the address is first looked up in g_check, the table of the device allocations the host side knows of (its own
+// buffers and the caller's, stag_hip.hip keeps it current): an access outside all of them is NOT made -- a load
+// gives zero, a store or DMA is dropped -- and the first such access leaves {count, line of this file, address,
+// bytes} in g_violation, which the host reads back after every call and reports as STAG_E_INVALID.  CHECK_THAT
+// does the same for a condition (loop bounds taken from memory, offsets into LDS).  Such a build cannot fault on
+// an index of its own making, so a run of the differential fuzz under it answers "kernel indexing or not".
+// ------------------------------------------------------------------------------------------
+#ifdef STAG_CHECKED
+constexpr int CHECK_MAX = 1024;
+struct CheckTable {
+    uint32_t n, pad;
+    uint64_t lo[CHECK_MAX], hi[CHECK_MAX];
+};
+__device__ CheckTable g_check;
+__device__ unsigned long long g_violation[4];
+__device__ __attribute__((noinline)) void violation(int line, uint64_t addr, uint64_t bytes) {
+    if (atomicAdd(&g_violation[0], 1ull) == 0ull) {
+        g_violation[1] = (unsigned long long)line;
+        g_violation[2] = addr;
+        g_violation[3] = bytes;
+    }
+}
+__device__ __attribute__((noinline)) bool chk(const void *p, size_t bytes, int line) {
+    const uint64_t a = (uint64_t)(uintptr_t)p;
+    const uint32_t n = g_check.n;
+    for (uint32_t i = 0; i < n; ++i)
+        if (a >= g_check.lo[i] && a + bytes <= g_check.hi[i]) return true;
+    violation(line, a, bytes);
+    return false;
+}
+template <typename T>
+__device__ __forceinline__ T checked_load(const T *p, int line) {
+    if (chk(p, sizeof(T), line)) return *p;
+    T zero;
+    __builtin_memset(&zero, 0, sizeof(T));
+    return zero;
+}
+template <typename T, typename V>
+__device__ __forceinline__ void checked_store(T *p, const V &v, int line) {
+    if (chk(p, sizeof(T), line)) *p = v;
+}
+__device__ __forceinline__ bool check_that(bool ok, int line, uint64_t a, uint64_t b) {
+    if (!ok) violation(-line, a, b);
+    return ok;
+}
+#define RD(arr, idx) checked_load(&(arr)[idx], __LINE__)
+#define RDC(arr, idx) checked_load(&(arr)[idx], __LINE__)
+#define RDK(arr, idx) checked_load(&(arr)[idx], __LINE__)   /* arr is already a STAG_CONST pointer */
+#define WR(arr, idx, v) checked_store(&(arr)[idx], (v), __LINE__)
+#define GUARD(ptr, bytes) chk((ptr), (bytes), __LINE__)
+#define CHECK_THAT(cond, a, b) check_that((cond), __LINE__, (uint64_t)(a), (uint64_t)(b))
+#else
+#define RD(arr, idx) ((arr)[idx])
+#define RDC(arr, idx) (as_const(arr)[idx])
+#define RDK(arr, idx) ((arr)[idx])
+#define WR(arr, idx, v) ((arr)[idx] = (v))
+#define GUARD(ptr, bytes) true
+#define CHECK_THAT(cond, a, b) true
+#endif
+
 #ifndef STAG_ABL
 #define STAG_ABL 0                // timing ablations of k_walk_level (tools/walk_ablations.sh); 0 = the product
 #endif
@@ -45,7 +109,11 @@ struct Entry {      // 16 bytes
 
 // Read-only tables are addressed through the constant address space: a wave-uniform address
 // then compiles to s_load_* (one fetch per wave into SGPRs) instead of a 64-lane vector load.
+#ifdef STAG_CHECKED
+#define STAG_CONST          /* plain loads, so that they can be checked */
+#else
 #define STAG_CONST __attribute__((address_space(4)))
+#endif
 template <typename T>
 __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
     return (const T STAG_CONST *)(uintptr_t)p;
@@ -220,7 +288,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
 
     // a record is clamped to the text buffer once, here: the loads below then need no bounds test of their own (a
     // 16-byte vector that starts before the record's end ends inside the buffer, whose size is a multiple of 16)
-    int64_t begin = live ? offs[seq] : 0, end = live ? (ends ? ends[seq] : offs[seq + 1]) : 0;
+    int64_t begin = live ? RD(offs, seq) : 0, end = live ? (ends ? RD(ends, seq) : RD(offs, seq + 1)) : 0;
     begin = max(begin, (int64_t)0);
     end = max(min(end, text_bytes), begin);
     const int64_t base = begin & ~(int64_t)15;
@@ -241,7 +309,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     const uint8_t *const src = text + begin;
     auto load16 = [&](int rel, uint32_t (&o)[4], uint32_t (&k)[4]) {
         uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (rel < len) v = *reinterpret_cast<const uint4 *>(src + rel);
+        if (rel < len) v = RD(reinterpret_cast<const uint4 *>(src + rel), 0);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         uint4 q = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
         if (rel < 0 || rel + 16 > len) {     // the record's first / last vector, or one past its end
@@ -422,20 +490,20 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                 else if (nb < 32) v[j] &= (1u << nb) - 1u;
             }
         }
-        *reinterpret_cast<uint4 *>(dst + w) = make_uint4(v[0], v[1], v[2], v[3]);
+        WR(reinterpret_cast<uint4 *>(dst + w), 0, make_uint4(v[0], v[1], v[2], v[3]));
     }
     if (live && gl == G - 1) {
-        if (win_out) win_out[seq] = (uint32_t)lo4 | ((uint32_t)hi4 << 16);
+        if (win_out) WR(win_out, seq, (uint32_t)lo4 | ((uint32_t)hi4 << 16));
         int st = 0;  // STAG_SEQ_OK
         if (running == 0) st = 5;
         // min_perc <= 0 (the default of `stag classify`): aligned / running * 100 >= 0 holds for every record
         // (a NaN threshold still fails every record)
         else if (!(min_perc <= 0.0) && !((double)aligned / (double)running * 100.0 >= min_perc)) st = 6;
         else if ((int64_t)running * 5 != L) st = 7;
-        if (pre_status && pre_status[seq]) st = pre_status[seq];
-        n_char_out[seq] = running;
-        n_aligned_out[seq] = aligned;
-        status_out[seq] = st;
+        if (pre_status && RD(pre_status, seq)) st = RD(pre_status, seq);
+        WR(n_char_out, seq, running);
+        WR(n_aligned_out, seq, aligned);
+        WR(status_out, seq, st);
     }
 }
 
@@ -458,22 +526,22 @@ __global__ __launch_bounds__(256) void k_backtranslate(const uint8_t *__restrict
     const int lane = threadIdx.x & 63;
     const int64_t rec = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (rec >= n) return;
-    const int64_t p0 = prot_offs[rec], p1 = prot_offs[rec + 1];
-    const int64_t g0 = gene_offs[rec], glen = gene_offs[rec + 1] - g0;
+    const int64_t p0 = RD(prot_offs, rec), p1 = RD(prot_offs, rec + 1);
+    const int64_t g0 = RD(gene_offs, rec), glen = RD(gene_offs, rec + 1) - g0;
     const int64_t o0 = 3 * p0;
     if (check_length) {
         int64_t residues = 0;   // every character that is not '-' (align.py:65)
-        for (int64_t p = p0 + lane; p < p1; p += 64) residues += prot[p] != '-';
+        for (int64_t p = p0 + lane; p < p1; p += 64) residues += RD(prot, p) != '-';
         residues = wave_sum((int)residues);
         if (glen != 3 * residues && glen - 3 != 3 * residues) {
-            if (lane == 0) { out_begin[rec] = o0; out_end[rec] = o0; status[rec] = 8; }
+            if (lane == 0) { WR(out_begin, rec, o0); WR(out_end, rec, o0); WR(status, rec, 8); }
             return;
         }
     }
     int64_t consumed = 0, emitted = 0;   // residues that took a codon / characters written, before this step
     for (int64_t base = p0; base < p1; base += 64) {
         const int64_t p = base + lane;
-        const uint8_t c = p < p1 ? prot[p] : (uint8_t)'.';
+        const uint8_t c = p < p1 ? RD(prot, p) : (uint8_t)'.';
         const bool dash = c == '-', upper = c >= 'A' && c <= 'Z', lower = c >= 'a' && c <= 'z';
         const int takes = (upper || lower) ? 1 : 0;
         const int t_incl = wave_incl_scan(takes, lane);
@@ -483,11 +551,11 @@ __global__ __launch_bounds__(256) void k_backtranslate(const uint8_t *__restrict
         else if (upper) e = (int)min((int64_t)3, max((int64_t)0, glen - g));   // a slice past the end is shorter
         const int e_incl = wave_incl_scan(e, lane);
         uint8_t *dst = out + o0 + emitted + (e_incl - e);
-        for (int j = 0; j < e; ++j) dst[j] = dash ? (uint8_t)'-' : gene[g0 + g + j];
+        for (int j = 0; j < e; ++j) WR(dst, j, dash ? (uint8_t)'-' : RD(gene, g0 + g + j));
         consumed += __shfl(t_incl, 63);
         emitted += __shfl(e_incl, 63);
     }
-    if (lane == 0) { out_begin[rec] = o0; out_end[rec] = o0 + emitted; status[rec] = 0; }
+    if (lane == 0) { WR(out_begin, rec, o0); WR(out_end, rec, o0 + emitted); WR(status, rec, 0); }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -509,7 +577,7 @@ __global__ __launch_bounds__(256) void k_parse_onehot(const uint8_t *__restrict_
     const int lane = threadIdx.x & 63;
     const int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (line >= n) return;
-    const int64_t b = body_begin[line], e = body_end[line];
+    const int64_t b = RD(body_begin, line), e = RD(body_end, line);
     const int64_t blen = e - b;                  // "x\tx\t...x": 2 nf - 1 bytes
     const bool form = b >= 0 && e <= text_bytes && blen > 0 && (blen & 1) && (blen + 1) / 2 <= 0x7fffffff;
     const int64_t nf = form ? (blen + 1) / 2 : 0;
@@ -531,7 +599,7 @@ __global__ __launch_bounds__(256) void k_parse_onehot(const uint8_t *__restrict_
 #pragma unroll
                 for (int i = 0; i < 17; ++i) {   // aligned dwords that hold bytes of the body
                     const int64_t at = base + 4 * i;
-                    d[i] = at < e ? *reinterpret_cast<const uint32_t *>(text + at) : 0u;
+                    d[i] = at < e ? RD(reinterpret_cast<const uint32_t *>(text + at), 0) : 0u;
                 }
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
@@ -546,15 +614,15 @@ __global__ __launch_bounds__(256) void k_parse_onehot(const uint8_t *__restrict_
                     word |= ((x & 1u) | ((x >> 15) & 2u)) << (2 * i);
                 }
             }
-            if (takes && w < W) row[w] = word;
+            if (takes && w < W) WR(row, w, word);
         }
     }
     const bool any_bad = __ballot(bad != 0u) != 0ull;
     if (!takes || any_bad)
-        for (int w = lane; w < W; w += 64) row[w] = 0u;
+        for (int w = lane; w < W; w += 64) WR(row, w, 0u);
     if (lane == 0) {
-        n_fields[line] = (int32_t)nf;
-        flag[line] = (!form || any_bad) ? 1 : 0;
+        WR(n_fields, line, (int32_t)nf);
+        WR(flag, line, (!form || any_bad) ? 1 : 0);
     }
 }
 
@@ -572,7 +640,7 @@ __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restric
         const int w = w0 + lane;
         bool differs = false;
         if (w < W) {
-            const uint32_t x = row[w], r0 = r0_word(w, L);
+            const uint32_t x = RD(row, w), r0 = r0_word(w, L);
             gaps += __popc(x & r0);
             differs = x != r0;
         }
@@ -584,8 +652,8 @@ __global__ __launch_bounds__(256) void k_count_aligned(const uint32_t *__restric
     }
     gaps = wave_sum(gaps);
     if (lane == 0) {
-        n_aligned[seq] = (L + 4) / 5 - gaps;
-        if (win_out) win_out[seq] = hi > lo ? (uint32_t)(lo >> 2) | ((uint32_t)((hi + 3) >> 2) << 16) : 0xffffu;
+        WR(n_aligned, seq, (L + 4) / 5 - gaps);
+        if (win_out) WR(win_out, seq, hi > lo ? (uint32_t)(lo >> 2) | ((uint32_t)((hi + 3) >> 2) << 16) : 0xffffu);
     }
 }
 
@@ -607,25 +675,25 @@ __global__ __launch_bounds__(256) void k_concat_bits(int64_t n_genomes, int n_ge
     int a = 0, b = n_genes;   // first gene whose bits end after lo
     while (a < b) {
         const int m = (a + b) >> 1;
-        if (goff[m + 1] > lo) b = m; else a = m + 1;
+        if (RD(goff, m + 1) > lo) b = m; else a = m + 1;
     }
     uint32_t v = 0;
-    for (int p = a; p < n_genes && goff[p] < hi; ++p) {
-        const int r = src_row[j * n_genes + p];
+    for (int p = a; p < n_genes && RD(goff, p) < hi; ++p) {
+        const int r = RD(src_row, j * n_genes + p);
         if (r < 0) continue;
-        const int64_t d0 = max(lo, goff[p]), d1 = min(hi, goff[p + 1]);
+        const int64_t d0 = max(lo, RD(goff, p)), d1 = min(hi, RD(goff, p + 1));
         const int nb = (int)(d1 - d0);
         if (nb <= 0) continue;
-        const int64_t s0 = d0 - goff[p];
-        const int wpr = src_wpr[p];
-        const uint32_t *row = arena + src_base[p] + (int64_t)r * wpr;
+        const int64_t s0 = d0 - RD(goff, p);
+        const int wpr = RD(src_wpr, p);
+        const uint32_t *row = arena + RD(src_base, p) + (int64_t)r * wpr;
         const int i = (int)(s0 >> 5), sh = (int)(s0 & 31);
-        uint32_t x = row[i] >> sh;
-        if (sh && i + 1 < wpr) x |= row[i + 1] << (32 - sh);
+        uint32_t x = RD(row, i) >> sh;
+        if (sh && i + 1 < wpr) x |= RD(row, i + 1) << (32 - sh);
         if (nb < 32) x &= (1u << nb) - 1u;
         v |= x << (int)(d0 - lo);
     }
-    out[j * W_out + w] = v;
+    WR(out, j * W_out + w, v);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -636,7 +704,7 @@ __global__ __launch_bounds__(256) void k_concat_bits(int64_t n_genomes, int n_ge
 __global__ __launch_bounds__(256) void k_init_status(int64_t n, const int32_t *__restrict__ status_in,
                                                      int32_t *__restrict__ status) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (s < n) status[s] = status_in ? status_in[s] : 0;
+    if (s < n) WR(status, s, status_in ? RD(status_in, s) : 0);
 }
 
 // pos[s] = rank of s among the sequences of its node, count[node] = sequences at that node.
@@ -673,17 +741,17 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
         nd[j] = -1;
         if (s < n) {
             if (prev) {
-                nd[j] = prev[s].node;
+                nd[j] = RD(&prev[s].node, 0);
             } else {
-                const int st = status_in ? status_in[s] : 0;
-                status[s] = st;
+                const int st = status_in ? RD(status_in, s) : 0;
+                WR(status, s, st);
                 nd[j] = st == 0 ? 0 : -1;
             }
             if (nd[j] < lo || nd[j] >= hi) {
                 nd[j] = -1;
-                cur[s].node = -1;
+                WR(&cur[s].node, 0, -1);
             }
-            node[s] = nd[j];
+            WR(node, s, nd[j]);
         }
     }
     const int nbins = hi - lo;
@@ -728,7 +796,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
                 c[u] = b < nbins ? s_cnt[b] : 0;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) r[u] = c[u] ? atomicAdd(&count[lo + b0 + u * ASSIGN_THREADS], c[u]) : 0;
+            for (int u = 0; u < 4; ++u)
+                r[u] = c[u] && GUARD(&count[lo + b0 + u * ASSIGN_THREADS], 4) ? atomicAdd(&count[lo + b0 + u * ASSIGN_THREADS], c[u]) : 0;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int b = b0 + u * ASSIGN_THREADS;
@@ -738,7 +807,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < ASSIGN_ITEMS; ++j)
-            if (nd[j] >= 0) pos[s0 + (int64_t)j * ASSIGN_THREADS] = s_cnt[nd[j] - lo] + rank[j];
+            if (nd[j] >= 0) WR(pos, s0 + (int64_t)j * ASSIGN_THREADS, s_cnt[nd[j] - lo] + rank[j]);
         return;
     }
 #pragma unroll
@@ -761,9 +830,9 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
             }
         }
         int base = 0;
-        if (ndj >= 0 && lane == leader_lane) base = atomicAdd(&count[ndj], cnt);
+        if (ndj >= 0 && lane == leader_lane && GUARD(&count[ndj], 4)) base = atomicAdd(&count[ndj], cnt);
         base = __shfl(base, leader_lane);
-        if (ndj >= 0) pos[s0 + (int64_t)j * ASSIGN_THREADS] = base + rk;
+        if (ndj >= 0) WR(pos, s0 + (int64_t)j * ASSIGN_THREADS, base + rk);
     }
 }
 
@@ -773,7 +842,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(int64_t n, int lo, in
 // other nodes get walk tasks.
 __device__ __forceinline__ bool node_is_trivial(const int32_t *__restrict__ child_first,
                                                 const uint8_t *__restrict__ node_err, int nd) {
-    return child_first[nd + 1] - child_first[nd] <= 1 || node_err[nd] != 0;
+    return RD(child_first, nd + 1) - RD(child_first, nd) <= 1 || RD(node_err, nd) != 0;
 }
 
 // One workgroup: exclusive scan of the task counts over the nodes [lo, hi) of one level.
@@ -788,7 +857,7 @@ __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int per = (hi - lo + 1023) / 1024;
     const int i0 = lo + t * per, i1 = min(hi, i0 + per);
-    auto tasks_of = [&](int i) { return node_is_trivial(child_first, node_err, i) ? 0 : (count[i] + TILE - 1) / TILE; };
+    auto tasks_of = [&](int i) { return node_is_trivial(child_first, node_err, i) ? 0 : (RD(count, i) + TILE - 1) / TILE; };
     int sb = 0;
     for (int i = i0; i < i1; ++i) sb += tasks_of(i);
     const int ib = wave_incl_scan(sb, lane);
@@ -801,10 +870,10 @@ __global__ __launch_bounds__(1024) void k_scan_level(int lo, int hi, const int32
     }
     int rb = base_b + ib - sb;
     for (int i = i0; i < i1; ++i) {
-        task_off[i] = rb;
+        WR(task_off, i, rb);
         rb += tasks_of(i);
     }
-    if (t == 0) *n_tasks = tot_b;
+    if (t == 0) WR(n_tasks, 0, tot_b);
 }
 
 // What a trivial node decides for every sequence standing on it (see node_is_trivial).
@@ -813,14 +882,14 @@ __device__ __forceinline__ void settle_trivial(int c0, int k, int err, int64_t s
     LevelRec r;
     r.pad = 0;
     if (err) {            // the reference raises here (classify.py:40 / :24-25)
-        status[s] = err;
+        WR(status, s, err);
         r.node = -1; r.prob = 0.0;
     } else if (k == 1) {  // classify.py:36-37: the only child, placeholder score 2, classifier not evaluated
         r.node = c0; r.prob = 2.0;
     } else {              // a leaf: the walk ends (classify.py:34-35)
         r.node = -1; r.prob = 0.0;
     }
-    cur[s] = r;
+    WR(cur, s, r);
 }
 
 // Tables a grouping kernel needs to resolve a task's hints.
@@ -844,19 +913,19 @@ __device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint
     int hA = 0, hB = 0;
     if (h4 > l4) { hA = l4 >> 2; hB = min((h4 + 3) >> 2, h.NC); }
     tk.hA = hA; tk.hB = hB;
-    const bool mfma = h.mfma_ok && h.mfma_ok[nd];
+    const bool mfma = h.mfma_ok && RD(h.mfma_ok, nd);
     tk.mfma = mfma ? 1 : 0;
     tk.dig_at = 0; tk.U = 0; tk.f0 = 0; tk.nf = 0; tk.qscale = 0.0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) tk.unused[j] = 0;
     if (mfma) {
         const uint32_t *po = h.pf_off + (size_t)nd * h.NC;
-        const uint32_t first = po[0], f0 = po[hA], f1 = po[hB];
-        tk.U = h.dig_ld[nd];
+        const uint32_t first = RD(po, 0), f0 = RD(po, hA), f1 = RD(po, hB);
+        tk.U = RD(h.dig_ld, nd);
         tk.f0 = f0;
         tk.nf = f1 - f0;
-        tk.dig_at = h.dig_base[nd] + (f0 - first);
-        tk.qscale = h.qscale[nd];
+        tk.dig_at = RD(h.dig_base, nd) + (f0 - first);
+        tk.qscale = RD(h.qscale, nd);
     }
     return tk;
 }
@@ -871,20 +940,20 @@ __global__ __launch_bounds__(256) void k_scatter(int64_t n, int lo, int hi, cons
                                                  HintTables hints) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const int nd = node[s];
+    const int nd = RD(node, s);
     if (nd < lo || nd >= hi) return;
-    const int c0 = child_first[nd], k = child_first[nd + 1] - c0, err = node_err[nd];
+    const int c0 = RD(child_first, nd), k = RD(child_first, nd + 1) - c0, err = RD(node_err, nd);
     if (k <= 1 || err) {
         settle_trivial(c0, k, err, s, cur, status);
         return;
     }
-    const int p = pos[s];
-    const int task = task_off[nd] + p / TILE;
+    const int p = RD(pos, s);
+    const int task = RD(task_off, nd) + p / TILE;
     SeqRef ref;
     ref.seq = (int32_t)s;
-    ref.win = win[s];
-    order[(size_t)task * TILE + (p & (TILE - 1))] = ref;
-    if ((p & (TILE - 1)) == 0) tasks[task] = make_task(nd, min(TILE, count[nd] - p), c0, k, ref.win, hints);
+    ref.win = RD(win, s);
+    WR(order, (size_t)task * TILE + (p & (TILE - 1)), ref);
+    if ((p & (TILE - 1)) == 0) WR(tasks, task, make_task(nd, min(TILE, RD(count, nd) - p), c0, k, ref.win, hints));
 }
 
 // Level 0 needs no grouping: every sequence whose incoming status is OK stands on the root, so
@@ -898,19 +967,19 @@ __global__ __launch_bounds__(256) void k_root_level(int64_t n, const int32_t *__
                                                     HintTables hints) {
     const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (s >= n) return;
-    const int st = status_in ? status_in[s] : 0;
-    status[s] = st;
-    const int c0 = child_first[0], k = child_first[1] - c0, err = node_err[0];
+    const int st = status_in ? RD(status_in, s) : 0;
+    WR(status, s, st);
+    const int c0 = RD(child_first, 0), k = RD(child_first, 1) - c0, err = RD(node_err, 0);
     const bool trivial = k <= 1 || err;
-    if (st != 0) cur[s].node = -1;
+    if (st != 0) WR(&cur[s].node, 0, -1);
     else if (trivial) settle_trivial(c0, k, err, s, cur, status);
-    if (s == 0) *n_tasks = trivial ? 0 : (int32_t)((n + TILE - 1) / TILE);
+    if (s == 0) WR(n_tasks, 0, trivial ? 0 : (int32_t)((n + TILE - 1) / TILE));
     if (trivial) return;
     SeqRef ref;
     ref.seq = st == 0 ? (int32_t)s : -1;
-    ref.win = win[s];
-    order[s] = ref;
-    if ((s & (TILE - 1)) == 0) tasks[s / TILE] = make_task(0, (int32_t)min((int64_t)TILE, n - s), c0, k, ref.win, hints);
+    ref.win = RD(win, s);
+    WR(order, s, ref);
+    if ((s & (TILE - 1)) == 0) WR(tasks, s / TILE, make_task(0, (int32_t)min((int64_t)TILE, n - s), c0, k, ref.win, hints));
 }
 
 // ------------------------------------------------------------------------------------------
@@ -979,6 +1048,11 @@ __device__ __forceinline__ int wave_max_i(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// (checked build) does the byte offset `off` of a row word lie in the chunks [sA, sB) that are staged?
+__device__ __forceinline__ bool in_slice(uint32_t off, int sA, int sB) {
+    return off >= (uint32_t)sA * (CHUNK_WORDS * 4) && off < (uint32_t)sB * (CHUNK_WORDS * 4) && (off & 3u) == 0u;
+}
+
 // entry en = {off, bit, w_lo, w_hi} in VGPRs (same value in every lane): w if this lane's row
 // has the feature, else +0.0
 __device__ __forceinline__ double masked_weight_v(const char *my_row, const uint4 en) {
@@ -1013,11 +1087,11 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[WALK_LDS_WORDS];
 
     const int lane = threadIdx.x & 63;
-    const int n_tasks = *as_const(a.n_tasks);
-    const i32x8 tk = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x];
+    const int n_tasks = RDC(a.n_tasks, 0);
+    const i32x8 tk = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x);
     // the task's slots of order[] sit at a fixed place: fetched together with the task record
     // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
-    SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];
+    SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);
     if ((int)blockIdx.x >= n_tasks) return;
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1034,7 +1108,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         r.node = node_out;
         r.pad = 0;
         r.prob = prob;
-        a.lvl[seq] = r;
+        WR(a.lvl, seq, r);
     };
 #if STAG_ABL == 5
     if (seq >= 0) put(c0, 0.5);
@@ -1091,13 +1165,14 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             for (int rr = 0; rr < TILE / NW; ++rr) {
                 // the row's sequence id as a scalar: its address is then computed once per wave
                 const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-                if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
+                const uint32_t *src = a.bits + ((size_t)s * a.W + w0) + lane;
+                if (s >= 0 && GUARD(src, 4)) dma4(src, &s_rows[(rr * NW + wave) * stride]);
             }
         }
     };
     // up to `half` coefficients from e_lo on -> buffer `buf` of this wave's piece (wave-private)
     auto fetch_ent = [&](uint32_t e_lo, uint32_t e_hi, int buf) {
-        if (lane < half && e_lo + lane < e_hi) dma16(a.blocks + e_lo + lane, s_ent + buf * half);
+        if (lane < half && e_lo + lane < e_hi && GUARD(a.blocks + e_lo + lane, 16)) dma16(a.blocks + e_lo + lane, s_ent + buf * half);
     };
     // z += the sibling's chunk sums over the slice [sA, sB); its first `half` coefficients are in buffer `buf`
     auto score_slice = [&](double &z, const uint32_t STAG_CONST *bo, uint32_t e_lo, uint32_t e_hi, int sA, int sB, int buf) {
@@ -1110,11 +1185,13 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         if (e_hi - e_lo <= (uint32_t)half) {
             // the usual case: every coefficient of the slice is in the buffer
             for (int ch = sA; ch < sB; ++ch) {
-                const uint32_t e0 = bo[ch] * BLOCK_ENTRIES - e_lo, e1 = bo[ch + 1] * BLOCK_ENTRIES - e_lo;
+                const uint32_t e0 = RDK(bo, ch) * BLOCK_ENTRIES - e_lo, e1 = RDK(bo, ch + 1) * BLOCK_ENTRIES - e_lo;
+                if (!CHECK_THAT(e0 <= e1 && e1 <= (uint32_t)half, e0, e1)) break;
                 double cs = 0.0;
                 for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
                     const uint4 *pe = &ent[e];   // wave-uniform address: LDS broadcast
                     const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                    if (!CHECK_THAT(in_slice(n0.x, sA, sB) && in_slice(n1.x, sA, sB) && in_slice(n2.x, sA, sB) && in_slice(n3.x, sA, sB), n0.x, sA)) break;
                     cs += masked_weight_v(my_row, n0);
                     cs += masked_weight_v(my_row, n1);
                     cs += masked_weight_v(my_row, n2);
@@ -1125,7 +1202,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         } else {
             uint32_t first = e_lo;   // first entry held in the buffer
             for (int ch = sA; ch < sB; ++ch) {
-                const uint32_t e0 = bo[ch] * BLOCK_ENTRIES, e1 = bo[ch + 1] * BLOCK_ENTRIES;
+                const uint32_t e0 = RDK(bo, ch) * BLOCK_ENTRIES, e1 = RDK(bo, ch + 1) * BLOCK_ENTRIES;
+                if (!CHECK_THAT(e_lo <= e0 && e0 <= e1 && e1 <= e_hi, e0, e1)) break;
                 double cs = 0.0;
                 for (uint32_t e = e0; e < e1; e += BLOCK_ENTRIES) {
                     if (e + BLOCK_ENTRIES > first + (uint32_t)half) {   // past the buffer: next stretch
@@ -1136,6 +1214,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                     }
                     const uint4 *pe = &ent[e - first];
                     const uint4 n0 = pe[0], n1 = pe[1], n2 = pe[2], n3 = pe[3];
+                    if (!CHECK_THAT(e >= first && in_slice(n0.x, sA, sB) && in_slice(n1.x, sA, sB) && in_slice(n2.x, sA, sB) && in_slice(n3.x, sA, sB), n0.x, sA)) break;
                     cs += masked_weight_v(my_row, n0);
                     cs += masked_weight_v(my_row, n1);
                     cs += masked_weight_v(my_row, n2);
@@ -1149,13 +1228,13 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
         const size_t base = (size_t)c * (a.NC + 1);
         int i_lo = own_lo, i_hi = own_hi;
         asm volatile("" : "+v"(i_lo), "+v"(i_hi));   // keeps the two 64-bit addresses out of long-lived registers
-        return a.gappre[base + i_lo] + a.gapsuf[base + i_hi];
+        return RD(a.gappre, base + i_lo) + RD(a.gapsuf, base + i_hi);
     };
     auto decide = [&](double z, int c) {
 #if STAG_ABL == 2
-        const double p = z + as_const(a.intercept)[c];
+        const double p = z + RDC(a.intercept, c);
 #else
-        const double p = sigmoid(z + as_const(a.intercept)[c]);
+        const double p = sigmoid(z + RDC(a.intercept, c));
 #endif
         if (p > best_p) { best_p = p; best_c = c; }  // strict '>' in stored order
     };
@@ -1174,8 +1253,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 #endif
             if (windowed) {
                 const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave) * a.NC;
-                e_lo = bo[wA] * BLOCK_ENTRIES;
-                e_hi = bo[wB] * BLOCK_ENTRIES;
+                e_lo = RDK(bo, wA) * BLOCK_ENTRIES;
+                e_hi = RDK(bo, wB) * BLOCK_ENTRIES;
             }
         }
         if (windowed) {
@@ -1185,8 +1264,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
             fetch_ent(e_lo, e_hi, 0);        // in flight together with the rows
             if (n_mine > 1) {
                 const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + wave + NW) * a.NC;
-                ne_lo = bo[wA] * BLOCK_ENTRIES;
-                ne_hi = bo[wB] * BLOCK_ENTRIES;
+                ne_lo = RDK(bo, wA) * BLOCK_ENTRIES;
+                ne_hi = RDK(bo, wB) * BLOCK_ENTRIES;
             }
             __syncthreads();                 // drains the DMA of every wave, then the barrier
         }
@@ -1202,8 +1281,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                     fetch_ent(ne_lo, ne_hi, (i + 1) & 1);        // that half's last reader was sibling i - 1
                     if (i + 2 < n_mine) {
                         const uint32_t STAG_CONST *bo2 = blk_off + (size_t)(c + 2 * NW) * a.NC;
-                        nn_lo = bo2[wA] * BLOCK_ENTRIES;
-                        nn_hi = bo2[wB] * BLOCK_ENTRIES;
+                        nn_lo = RDK(bo2, wA) * BLOCK_ENTRIES;
+                        nn_hi = RDK(bo2, wB) * BLOCK_ENTRIES;
                     }
                 }
             }
@@ -1236,8 +1315,8 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
                     e_lo[j] = e_hi[j] = 0;
                     if (pg0 + j * NW + wave < k) {   // wave-uniform
                         const uint32_t STAG_CONST *bo = blk_off + (size_t)(c0 + pg0 + j * NW + wave) * a.NC;
-                        e_lo[j] = bo[sA] * BLOCK_ENTRIES;
-                        e_hi[j] = bo[sB] * BLOCK_ENTRIES;
+                        e_lo[j] = RDK(bo, sA) * BLOCK_ENTRIES;
+                        e_hi[j] = RDK(bo, sB) * BLOCK_ENTRIES;
                     }
                 }
                 __syncthreads();   // everyone is done reading the previous slice (rows and coefficients)
@@ -1333,10 +1412,10 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
     unsigned long long phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_ = __builtin_readcyclecounter();
 #endif
-    const int n_tasks = *as_const(a.n_tasks);
-    const i32x8 t0 = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x];
-    const i32x8 t2 = as_const(reinterpret_cast<const i32x8 *>(a.tasks))[4 * blockIdx.x + 2];
-    SeqRef me = a.order[(size_t)blockIdx.x * TILE + lane];     // lane = row of the task (staging, X)
+    const int n_tasks = RDC(a.n_tasks, 0);
+    const i32x8 t0 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x);
+    const i32x8 t2 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x + 2);
+    SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);     // lane = row of the task (staging, X)
     if ((int)blockIdx.x >= n_tasks) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int node = t0[0], count = t0[1], c0 = t0[2], k = t0[3];
@@ -1375,10 +1454,10 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
     const int8_t *dig_node = nullptr;                           // column 0, first feature of the node
     uint32_t pf_first = 0;
     if (!hinted) {
-        U = as_const(m.dig_ld)[node];
-        qs = as_const(m.qscale)[node];
-        dig_node = m.dig + as_const(m.dig_base)[node];
-        pf_first = as_const(m.pf_off)[(size_t)node * a.NC];
+        U = RDC(m.dig_ld, node);
+        qs = RDC(m.qscale, node);
+        dig_node = m.dig + RDC(m.dig_base, node);
+        pf_first = RDC(m.pf_off, (size_t)node * a.NC);
     }
 
     // ---- LDS: staged row words | X bytes; the C tile later overlays both
@@ -1405,9 +1484,9 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
         for (int h = 0; h < 2; ++h) {
             const int c = c0 + min(8 * rd + 4 * h + g, k - 1);
             const size_t base = (size_t)c * (a.NC + 1);
-            gp[h] = a.gappre[base + r_lo];
-            gs[h] = a.gapsuf[base + r_hi];
-            ic[h] = a.intercept[c];
+            gp[h] = RD(a.gappre, base + r_lo);
+            gs[h] = RD(a.gapsuf, base + r_hi);
+            ic[h] = RD(a.intercept, c);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h) kc[h] = (gp[h] + gs[h]) + ic[h];
@@ -1439,7 +1518,8 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
                     for (int rr = 0; rr < TILE / NW; ++rr) {
                         const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
 #if STAG_ABL != 7
-                        if (s >= 0) dma4(a.bits + ((size_t)s * a.W + w0) + lane, &s_rows[(rr * NW + wave) * stride]);
+                        const uint32_t *src = a.bits + ((size_t)s * a.W + w0) + lane;
+                        if (s >= 0 && GUARD(src, 4)) dma4(src, &s_rows[(rr * NW + wave) * stride]);
 #endif
                     }
                 }
@@ -1451,28 +1531,29 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
                 f1 = f0 + (uint32_t)t2[4];
                 dig_win = m.dig + (((uint64_t)(uint32_t)t2[1] << 32) | (uint32_t)t2[0]);
             } else {
-                f0 = as_const(m.pf_off)[(size_t)node * a.NC + sA];
-                f1 = as_const(m.pf_off)[(size_t)node * a.NC + sB];
+                f0 = RDC(m.pf_off, (size_t)node * a.NC + sA);
+                f1 = RDC(m.pf_off, (size_t)node * a.NC + sB);
                 dig_win = dig_node + (f0 - pf_first);
             }
             // this lane's own chunks inside the slice (bit i: chunk sA + i)
             const uint32_t own_mask = (own_hi > sA ? (own_hi - sA >= 32 ? 0xffffffffu : (1u << (own_hi - sA)) - 1u) : 0u) &
                                       ~(own_lo > sA ? (own_lo - sA >= 32 ? 0xffffffffu : (1u << (own_lo - sA)) - 1u) : 0u);
             const char *my_row = reinterpret_cast<const char *>(s_rows) + (lane * stride * 4 - sA * (CHUNK_WORDS * 4));
+            if (!CHECK_THAT(f0 <= f1 && f1 - f0 <= U, f0, f1)) break;
             for (uint32_t x0 = f0; x0 < f1; x0 += XK) {
                 // descriptors of this wave's features (scalar) and its digit fragments: in flight across the barrier
                 const uint32_t u0 = x0 + wave * per_wave;
                 i32x16 d0 = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, d1 = d0;
-                if (u0 < f1) d0 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0));
-                if (per_wave > 16 && u0 + 16 < f1) d1 = *as_const(reinterpret_cast<const i32x16 *>(m.pfeat + u0 + 16));
+                if (u0 < f1) d0 = RDC(reinterpret_cast<const i32x16 *>(m.pfeat + u0), 0);
+                if (per_wave > 16 && u0 + 16 < f1) d1 = RDC(reinterpret_cast<const i32x16 *>(m.pfeat + u0 + 16), 0);
                 const int nkb = min((int)((f1 - x0 + 63) >> 6), XK >> 6);
                 // branch-free (a wave without a column block, or a second 64-feature block that does not exist, re-reads
                 // a fragment that exists; those MFMAs are skipped below): loads in a branch would be waited for at its end
                 v4i bf[2];
                 {
                     const int8_t *bp = dig_win + (size_t)(16 * min(cb, ncb - 1) + (lane & 15)) * U + (x0 - f0) + 16 * (lane >> 4);
-                    bf[0] = *reinterpret_cast<const v4i *>(bp);
-                    bf[1] = *reinterpret_cast<const v4i *>(bp + (nkb > 1 ? 64 : 0));
+                    bf[0] = RD(reinterpret_cast<const v4i *>(bp), 0);
+                    bf[1] = RD(reinterpret_cast<const v4i *>(bp + (nkb > 1 ? 64 : 0)), 0);
                 }
                 STAG_STAMP(1);   // everything issued
                 __syncthreads();                           // rows landed (first build) / the previous X has been multiplied
@@ -1485,8 +1566,10 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
                         for (int h8 = 0; h8 < 16; h8 += 8) {   // eight LDS reads in flight together
                             uint32_t word[8];
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
+                            for (int i = 0; i < 8; ++i) {
+                                if (!CHECK_THAT(in_slice((uint32_t)d[h8 + i] & 0xffffu, sA, sB), d[h8 + i], sA)) { word[i] = 0u; continue; }
                                 word[i] = *reinterpret_cast<const uint32_t *>(my_row + ((uint32_t)d[h8 + i] & 0xffffu));
+                            }
                             if (uniform_win) {
 #pragma unroll
                                 for (int i = 0; i < 8; ++i)
@@ -1562,7 +1645,7 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
         rec.node = best_c;
         rec.pad = 0;
         rec.prob = sigmoid(best_raw);
-        a.lvl[myseq] = rec;
+        WR(a.lvl, myseq, rec);
     }
     STAG_STAMP(7);   // reduction, sigmoid, store
 #if STAG_ABL == 10
@@ -1595,13 +1678,13 @@ __global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int levels, i
     const int64_t s = s0 + threadIdx.x;
     if (threadIdx.x < cnt) {
         int sel = -1, lead = 0;
-        int st = status[s];
+        int st = RD(status, s);
         double *pp = s_pp + threadIdx.x * D;
         double *lp = s_lp + threadIdx.x * K;
         int32_t *pn = s_pn + threadIdx.x * D;
         int len = levels;
         for (int d = 0; d < levels; ++d) {   // independent loads; the walk ended at the first node < 0
-            const LevelRec r = lvl[(size_t)d * n + s];
+            const LevelRec r = RD(lvl, (size_t)d * n + s);
             pp[d] = r.prob;
             pn[d] = r.node;
             if (r.node < 0) len = min(len, d);
@@ -1628,16 +1711,16 @@ __global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int levels, i
                 const double STAG_CONST *row = tfc + (size_t)kk * (1 + n_tf);
                 double acc = 0.0;
                 if (len == n_tf) {
-                    for (int i = 0; i < len; ++i) acc += row[1 + i] * pp[i];
+                    for (int i = 0; i < len; ++i) acc += RDK(row, 1 + i) * pp[i];
                 } else if (len == 1) {
-                    for (int i = 0; i < n_tf; ++i) acc += row[1 + i] * pp[0];
+                    for (int i = 0; i < n_tf; ++i) acc += RDK(row, 1 + i) * pp[0];
                 } else if (n_tf == 1) {
-                    for (int i = 0; i < len; ++i) acc += row[1] * pp[i];
+                    for (int i = 0; i < len; ++i) acc += RDK(row, 1) * pp[i];
                 } else {
                     st = 3;
                     break;
                 }
-                const double p = sigmoid(acc + row[0]);
+                const double p = sigmoid(acc + RDK(row, 0));
                 lp[kk] = p;
                 if (p > best) { best = p; sel = kk; }
             }
@@ -1645,17 +1728,17 @@ __global__ __launch_bounds__(256) void k_rankcut(int64_t n, int D, int levels, i
         } else {
             for (int i = 0; i < D; ++i) pp[i] = 0.0;
         }
-        path_len[s] = len;
-        n_lead_single[s] = lead;
-        selected[s] = sel;
-        status[s] = st;
+        WR(path_len, s, len);
+        WR(n_lead_single, s, lead);
+        WR(selected, s, sel);
+        WR(status, s, st);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < cnt * D; i += 256) {
-        path_prob[(size_t)s0 * D + i] = s_pp[i];
-        path_node[(size_t)s0 * D + i] = s_pn[i];
+        WR(path_prob, (size_t)s0 * D + i, s_pp[i]);
+        WR(path_node, (size_t)s0 * D + i, s_pn[i]);
     }
-    for (int i = threadIdx.x; i < cnt * K; i += 256) level_prob[(size_t)s0 * K + i] = s_lp[i];
+    for (int i = threadIdx.x; i < cnt * K; i += 256) WR(level_prob, (size_t)s0 * K + i, s_lp[i]);
 }
 
 }  // namespace stagk

@@ -218,6 +218,12 @@ def compare_with_oracle(db, odb, res, out, X, classifiers):
     (1500, [[6], [2, 7], [1, 4]], 0.02, 700, "window"),                    # C2 row width, gap-padded reads
     (3200, [[5], [2, 3]], 0.01, 300, "zerofill"),                          # L=16000: 3 LDS chunks per row
     (64, [[11], [1, 17]], 0.5, 2000, "anybits"),                           # dense rows, wide fan-out, -s style bits
+    # windows wider than the walk's staging buffer (5 and 7 chunks) with rows dense enough that a slice's
+    # coefficients do not fit a wave's buffer: the slice-by-slice path of k_walk_level and its refill branch
+    (411, [[5], [2, 3, 18]], 0.3, 500, "onehot"),
+    (411, [[3], [2, 20]], 1.0, 300, "onehot"),
+    (700, [[4], [2, 3, 17]], 0.3, 400, "onehot"),
+    (700, [[2], [19, 3]], 1.0, 200, "anybits"),
 ])
 def test_classify_random_vs_oracle(ncol, fanouts, density, n, kind):
     rng = np.random.default_rng(ncol * 7 + n)
@@ -246,6 +252,57 @@ def test_classify_random_vs_oracle(ncol, fanouts, density, n, kind):
         res2 = db.classify_onehot(X[: n // 3])
         assert np.array_equal(res2.path_node, res.path_node[: n // 3])
         assert np.array_equal(res2.path_prob, res.path_prob[: n // 3])
+
+
+@pytest.mark.parametrize("ncol,density", [(411, 0.3), (411, 1.0), (700, 0.3), (700, 1.0)])
+def test_wide_dense_rows_text_and_packed_entries(ncol, density):
+    """The same wide, dense shapes through the TEXT entry point (whose rows are stored as window chunks only) and
+    through the packed-row entry point: full-length reads, reads with a window at either end, an all-gap read."""
+    rng = np.random.default_rng(ncol + int(10 * density))
+    L = 5 * ncol
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[3], [2, 18], [1, 2]], density)
+    strings = []
+    for i in range(260):
+        cols = rng.choice(list("ACGT-N"), size=ncol, p=[0.23, 0.23, 0.23, 0.23, 0.05, 0.03])
+        if i % 4 == 1:
+            cols[: int(rng.integers(1, ncol))] = "-"
+        if i % 4 == 2:
+            cols[int(rng.integers(1, ncol)):] = "-"
+        if i == 77:
+            cols[:] = "-"
+        strings.append("".join(cols))
+    X = np.stack([oracle_c.encode_a2m(s)[0] for s in strings])
+    odb = oracle_c.DenseDB(taxonomy, tax_function, classifiers, L)
+    out = odb.classify(X)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        text = db.classify_a2m(strings)                       # rows stay on the GPU, window chunks only
+        full = db.classify_a2m(strings, want_bits=True)       # whole rows
+        packed = db.classify_onehot(X)
+        compare_with_oracle(db, odb, packed, out, X, classifiers)
+        for f in ("status", "n_aligned", "path_len", "path_node", "path_prob", "selected", "level_prob"):
+            assert np.array_equal(getattr(text, f), getattr(packed, f)), f
+            assert np.array_equal(getattr(full, f), getattr(packed, f)), f
+        assert np.array_equal(tables.unpack_rows(full.bits, L), X)
+
+
+@pytest.mark.parametrize("strings", [[""], ["", ""], ["acgt"], ["", "acgt", ""], [""] * 70 + ["A-C"]],
+                         ids=["one-empty", "two-empty", "inserts-only", "mixed-empty", "many-empty-then-one"])
+def test_batches_of_empty_records(strings):
+    """A batch whose text is zero bytes long (one empty record as the whole batch: the configuration that left the
+    GPU faulted in the differential fuzz -- the encode buffers stayed unallocated for a text span of 0 bytes and
+    the encode kernel wrote its status to address 0), and its neighbours.  The reference raises ZeroDivisionError
+    for such a record (align.py:58)."""
+    rng = np.random.default_rng(1)
+    taxonomy, tax_function, classifiers = random_db(rng, 3, [[3], [2, 2]], 0.5)
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=15) as db:
+        for want_bits in (True, False):
+            res = db.classify_a2m(strings, want_bits=want_bits)
+            for i, s in enumerate(strings):
+                n_char = oracle_c.encode_a2m(s)[1]
+                assert res.n_char[i] == n_char
+                assert res.status[i] == (_lib.SEQ_ZERO_COLUMNS if n_char == 0 else _lib.SEQ_OK)
+            with pytest.raises(ZeroDivisionError):
+                raise_for_status(res.status)
 
 
 def test_classify_a2m_fused_vs_oracle():
