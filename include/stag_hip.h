@@ -166,6 +166,23 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
                           int64_t n, double min_perc_state, const stag_results_t *d_out, void *stream);
 
 /*
+ * The same for records whose flanking gap columns the host has dropped (align.py:37-58 again: a '-' column is
+ * 10000, which is what a row says wherever nothing else was written, so a run of '-' at either end of an aligned
+ * string only moves the column count).  Record i's aligned string = lead_trail[2 i] times '-', then
+ * text[offs[i] .. offs[i+1]), then lead_trail[2 i + 1] times '-'; every output is what stag_classify_a2m gives
+ * for that string (n_char counts the dropped columns too).  stag_fasta_scan_trim (stag_ingest.h) produces this
+ * form while it copies the records out of the aligner's stream: an amplicon read of 253 columns in a
+ * 1,500-column alignment travels to the GPU as 0.27 kB instead of 1.5 kB.  lead_trail may be NULL (nothing
+ * dropped: stag_classify_a2m).
+ */
+int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *offs, const int32_t *lead_trail,
+                              int64_t n, double min_perc_state, const stag_results_t *out, uint32_t *bits_out,
+                              int32_t *n_char_out);
+int stag_classify_a2m_trimmed_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
+                                  const int32_t *d_lead_trail, int64_t n, double min_perc_state,
+                                  const stag_results_t *d_out, void *stream);
+
+/*
  * NO COUNTERPART IN THE REFERENCE.  stag_classify_a2m_dev for callers that cannot allocate device
  * memory: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same
  * arguments, same kernels, same results, but the call allocates nothing (no hipMalloc, hipFree or

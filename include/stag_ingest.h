@@ -8,6 +8,7 @@
  *                           (stag/align.py:139-147): records of wrapped lines -> one string each
  *   stag_onehot_parse    <- stag/classify.py:16-20   alignment_reader: "id\t0\t1\t..." lines of a -s file
  *   stag_onehot_format   <- stag/classify.py:160-162 / stag/align.py:207  the -S writer
+ *   stag_rows_format_short <- stag/classify.py:182-190  the two-column output lines
  *
  * Streaming protocol (both parsers): the caller hands over whatever bytes it has; the parser
  * consumes whole records only and reports how many bytes it used.  The caller keeps the rest,
@@ -52,6 +53,17 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
                         stag_record_t *recs, int64_t *consumed, int64_t *text_used);
 
 /*
+ * The same scan for the trimmed form that stag_hip.h's stag_classify_a2m_trimmed takes: of each record's string
+ * (align.py:37-58's input) the run of '-' at its start and the run at its end are not copied to text_out;
+ * lead_trail[2 i] and lead_trail[2 i + 1] say how long they were (room for 2 * max_records values).  A '-' is a
+ * gap column whatever surrounds it, so nothing else about the record changes.  A record flagged
+ * STAG_INGEST_FALLBACK is re-parsed by the caller, who reports it untrimmed.  lead_trail == NULL: stag_fasta_scan.
+ */
+int64_t stag_fasta_scan_trim(const char *buf, int64_t len, int32_t final, int32_t at_start, int64_t max_records,
+                             char *text_out, int64_t text_cap, int64_t text_used_in, int64_t *offs,
+                             stag_record_t *recs, int64_t *consumed, int64_t *text_used, int32_t *lead_trail);
+
+/*
  * classify.py:16-20.  Lines end at '\n', '\r' or "\r\n" (text-mode universal newlines); each is
  * right-stripped, split at '\t'; the first field is the id, the others must be "0" or "1" for the
  * fast path.  Row i gets words_per_row uint32 words in bits_out (bit f -> word f>>5, bit f&31) when
@@ -79,6 +91,17 @@ int64_t stag_onehot_lines(const char *buf, int64_t len, int32_t final, int64_t m
  */
 int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, int32_t words_per_row,
                            const char *ids, const int64_t *id_off, char *out, int64_t out_cap);
+
+/*
+ * classify.py:182-190 for the short output: print(id, assigned lineage, sep="\t") per classified sequence.  Row i
+ * is written when key[i] >= 0 (a negative key: the sequence did not pass the filter, no line): its id is
+ * id_buf[id_begin[i] .. id_begin[i] + id_len[i]) -- the bytes stag_fasta_scan found, never turned into Python
+ * strings -- and its lineage is the string str_blob[str_off[key[i]] .. str_off[key[i] + 1]) (the caller builds one
+ * string per distinct (end position, selected level) of the batch).  Returns the bytes written, or
+ * -(bytes needed) - 1 when out_cap is too small.
+ */
+int64_t stag_rows_format_short(const char *id_buf, const int64_t *id_begin, const int64_t *id_len, const int32_t *key,
+                               int64_t n, const char *str_blob, const int64_t *str_off, char *out, int64_t out_cap);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,10 @@ EXPORTS = {
                                          ctypes.POINTER(Results), c_p, c_p]),
     "stag_classify_a2m_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.c_int64, ctypes.c_double,
                                              ctypes.POINTER(Results), c_p]),
+    "stag_classify_a2m_trimmed": (ctypes.c_int, [c_p, c_p, c_p, c_p, ctypes.c_int64, ctypes.c_double,
+                                                 ctypes.POINTER(Results), c_p, c_p]),
+    "stag_classify_a2m_trimmed_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, c_p, ctypes.c_int64, ctypes.c_double,
+                                                     ctypes.POINTER(Results), c_p]),
     "stag_classify_a2m_noalloc_dev": (ctypes.c_int, [c_p, c_p, ctypes.c_int64, c_p, ctypes.c_int64, ctypes.c_double,
                                                      ctypes.POINTER(Results), c_p]),
     "stag_backtranslate": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int64, ctypes.c_char_p, ctypes.c_int64,

@@ -113,18 +113,21 @@ def aligned_records(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
 
 
 def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose, size=None, ring_slots=2):
-    """Batches (ids, text uint8, offs int64, gene) of aligned records, parsed in C
+    """Batches (ids, text uint8, offs int64, gene, lead_trail) of aligned records, parsed in C
     (stag_amd.ingest.fasta_batches: no Python string per record).  gene is None for nucleotide
     databases (text/offs is the A2M alignment, for Database.classify_a2m_text); for protein
     databases text/offs is the protein alignment and gene = (gene text, gene offs) of the same
     records (align.py:148-158), for Database.classify_protein_a2m_text, which back-translates
-    on the GPU.  ring_slots: how many batches of a nucleotide database stay valid at a time (their text sits in a
+    on the GPU.  lead_trail (nucleotide databases; None for protein ones): the records come WITHOUT the run of
+    '-' at either end and lead_trail [n, 2] says how long those were (ingest.fasta_batches(trim=True)): the gap
+    columns around an amplicon read never travel to the GPU.  ring_slots: how many batches of a nucleotide database stay valid at a time (their text sits in a
     ring of page-locked buffers; the caller keeps ring_slots - 2 batches in flight)."""
     size = size or BATCH_RECORDS
     align_proc, parse_proc = _start_aligner(seq_file, protein_file, hmm_file, use_cmalign, n_threads, verbose)
     if not protein_file:
-        for ids, text, offs in ingest.fasta_batches(parse_proc.stdout, batch_records=size, pinned=True, ring_slots=ring_slots):
-            yield ids, text, offs, None
+        for ids, text, offs, lead_trail in ingest.fasta_batches(parse_proc.stdout, batch_records=size, pinned=True,
+                                                                ring_slots=ring_slots, trim=True):
+            yield ids, text, offs, None, lead_trail
         _finish_aligner(align_proc, parse_proc)
         return
     # The two streams are paired record by record, as the reference's zip() does (align.py:148): the batchers cut
@@ -178,12 +181,12 @@ def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
                 if clash:
                     pids, ptext, poffs = cut(P, clash)
                     gids, gtext, goffs = cut(G, clash)
-                    yield pids, ptext, poffs, (gtext, goffs)
+                    yield pids, ptext, poffs, (gtext, goffs), None
                 sys.stderr.write("[E::align] Error. protein and gene identifiers {} {} don't match.".format(bad_p, bad_g))
                 sys.exit(1)
             pids, ptext, poffs = cut(P, m)
             gids, gtext, goffs = cut(G, m)
-            yield pids, ptext, poffs, (gtext, goffs)
+            yield pids, ptext, poffs, (gtext, goffs), None
     _finish_aligner(align_proc, parse_proc)
 
 

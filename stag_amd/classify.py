@@ -163,9 +163,10 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
             want_bits = bool(save_ali_to_file) and rank == 0
             pending = collections.deque()
 
-            def run(d, text, offs, gene):
+            def run(d, text, offs, gene, lead_trail):
                 if gene is None:
-                    return d.classify_a2m_text(text, offs, min_perc_state=min_perc_state, want_bits=want_bits)
+                    return d.classify_a2m_text(text, offs, min_perc_state=min_perc_state, want_bits=want_bits,
+                                               lead_trail=lead_trail)
                 # protein database: back-translation happens on the GPU (align.py:63-94)
                 return d.classify_protein_a2m_text(text, offs, gene[0], gene[1], min_perc_state=min_perc_state,
                                                    want_bits=want_bits)
@@ -198,12 +199,12 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                         packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
 
             with alignment_out:
-                for b, (ids, text, offs, gene) in enumerate(batches):
+                for b, (ids, text, offs, gene, lead_trail) in enumerate(batches):
                     mine = parallel.owner_of_batch(b, world) == rank
                     if not mine and not want_bits and (state["alignment_length"] or pending):
                         continue
                     pending.append((b, mine, ids, text, offs, gene,
-                                    pool.submit(lambda d, t=text, o=offs, g=gene: run(d, t, o, g))))
+                                    pool.submit(lambda d, t=text, o=offs, g=gene, lt=lead_trail: run(d, t, o, g, lt))))
                     while len(pending) >= _in_flight(pool):
                         finish_oldest()
                 while pending:

@@ -268,6 +268,7 @@ struct stag_db {
     struct Slot {
         DevBuf<uint8_t> text;
         DevBuf<int64_t> offs;
+        DevBuf<int32_t> lead_trail;
         DevBuf<int32_t> path_node, path_len, lead, selected, n_aligned, status, n_char;
         DevBuf<double> path_prob, level_prob;
         DevBuf<uint32_t> bits;
@@ -291,7 +292,7 @@ struct stag_db {
         for (auto &r : recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
         recs.clear();
         for (auto &sl : slot) {
-            sl.text.release(); sl.offs.release(); sl.path_node.release(); sl.path_len.release(); sl.lead.release();
+            sl.text.release(); sl.offs.release(); sl.lead_trail.release(); sl.path_node.release(); sl.path_len.release(); sl.lead.release();
             sl.selected.release(); sl.n_aligned.release(); sl.status.release(); sl.n_char.release();
             sl.path_prob.release(); sl.level_prob.release(); sl.bits.release();
             for (hipEvent_t *e : {&sl.up, &sl.done, &sl.down})
@@ -370,7 +371,7 @@ int launch_check(const char *what) {
 int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
                double min_perc, uint32_t *d_bits, int32_t *d_n_char, int32_t *d_n_aligned, int32_t *d_status,
                uint32_t *d_win, hipStream_t st, const int64_t *d_ends = nullptr, const int32_t *d_pre_status = nullptr,
-               bool full_rows = true) {
+               bool full_rows = true, const int32_t *d_lead_trail = nullptr) {
     if (n == 0) return STAG_OK;
     const int W = stag_words_per_row(L);
     // (a kernel handed a null output would write to address 0: a GPU memory fault, not an error code)
@@ -384,7 +385,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
     CHK_TEMP_CLEAR();
     CHK_TEMP(d_text, text_bytes); CHK_TEMP(d_offs, (n + (d_ends ? 0 : 1)) * 8); CHK_TEMP(d_ends, n * 8);
     CHK_TEMP(d_bits, (size_t)n * W * 4); CHK_TEMP(d_n_char, n * 4); CHK_TEMP(d_n_aligned, n * 4); CHK_TEMP(d_status, n * 4);
-    CHK_TEMP(d_win, n * 4); CHK_TEMP(d_pre_status, n * 4);
+    CHK_TEMP(d_win, n * 4); CHK_TEMP(d_pre_status, n * 4); CHK_TEMP(d_lead_trail, n * 8);
     CHK_UPLOAD();
     // lanes per record: the candidate that wastes the fewest lane slots on an average record
     // (ties go to the wider group: fewer, longer-lived rows in LDS)
@@ -408,7 +409,7 @@ int encode_dev(stag_db *db_for_prof, int L, const char *d_text, int64_t text_byt
         Prof p(db_for_prof, st, 0);
         trace_launch(st, "k_encode_a2m G=%d full=%d n=%lld L=%d W=%d text_bytes=%lld grid=%lld lds=%zu", G, (int)(full_rows || !d_win), (long long)n, L, W, (long long)text_bytes, (long long)grid, lds);
         hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(256), lds, st, (const uint8_t *)d_text, text_bytes,
-                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win, d_ends, d_pre_status);
+                           d_offs, n, L, W, min_perc, d_bits, d_n_char, d_n_aligned, d_status, d_win, d_ends, d_pre_status, d_lead_trail);
         return STAG_OK;
     };
     // full_rows: the caller reads the rows (stag_encode_a2m*, bits_out); otherwise only the walk does, and it
@@ -1084,8 +1085,9 @@ int stag_onehot_text_classify(stag_db_t *db, int64_t n, const int64_t *patch_ind
     return copy_results_to_host(db, out, n, nullptr);
 }
 
-int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
-                          double min_perc_state, const stag_results_t *d_out, void *stream) {
+int stag_classify_a2m_trimmed_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs,
+                                  const int32_t *d_lead_trail, int64_t n, double min_perc_state,
+                                  const stag_results_t *d_out, void *stream) {
     if (!db || n < 0 || (n > 0 && (!d_text || !d_offs))) return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
     HIP_TRY(hipSetDevice(db->device));
@@ -1094,9 +1096,14 @@ int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes,
     const Out o = resolve(db, d_out);
     hipStream_t st = (hipStream_t)stream;
     if ((rc = encode_dev(db, db->L, d_text, text_bytes, d_offs, n, min_perc_state, db->bits.p, db->enc_n_char.p,
-                         o.n_aligned, db->enc_status.p, db->win.p, st, nullptr, nullptr, /*full_rows=*/false)))
+                         o.n_aligned, db->enc_status.p, db->win.p, st, nullptr, nullptr, /*full_rows=*/false, d_lead_trail)))
         return rc;
     return walk_dev(db, work_of(db), db->bits.p, n, db->enc_status.p, o, false, st);
+}
+
+int stag_classify_a2m_dev(stag_db_t *db, const char *d_text, int64_t text_bytes, const int64_t *d_offs, int64_t n,
+                          double min_perc_state, const stag_results_t *d_out, void *stream) {
+    return stag_classify_a2m_trimmed_dev(db, d_text, text_bytes, d_offs, nullptr, n, min_perc_state, d_out, stream);
 }
 
 // Same kernels as stag_classify_a2m_dev; the workspace and any output the caller left NULL come out
@@ -1160,10 +1167,21 @@ int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t tex
 
 int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n, double min_perc_state,
                       const stag_results_t *out, uint32_t *bits_out, int32_t *n_char_out) {
+    return stag_classify_a2m_trimmed(db, text, offs, nullptr, n, min_perc_state, out, bits_out, n_char_out);
+}
+
+int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *offs, const int32_t *lead_trail, int64_t n,
+                              double min_perc_state, const stag_results_t *out, uint32_t *bits_out, int32_t *n_char_out) {
     if (!db || n < 0 || !out || (n > 0 && (!text || !offs || !out->status))) return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
     int rc;
     if ((rc = check_offsets(offs, n, "offs"))) return rc;
+    if (lead_trail)
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t cols = (int64_t)lead_trail[2 * i] + lead_trail[2 * i + 1] + (offs[i + 1] - offs[i]);
+            if (lead_trail[2 * i] < 0 || lead_trail[2 * i + 1] < 0 || cols > 0x7fffffff)
+                return fail(STAG_E_INVALID, "lead_trail of record %lld: counts must be non-negative and the record shorter than 2^31 columns", (long long)i);
+        }
     HIP_TRY(hipSetDevice(db->device));
     // ---- sub-batches: cut at record boundaries, at most PIPE_RECORDS records / PIPE_BYTES bytes each
     const int64_t PIPE_RECORDS = pipe_records(), PIPE_BYTES = (int64_t)96 << 20;
@@ -1211,6 +1229,7 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
             (rc = sl.path_prob.reserve(max_m * D)) || (rc = sl.path_len.reserve(max_m)) || (rc = sl.lead.reserve(max_m)) ||
             (rc = sl.level_prob.reserve(max_m * K)) || (rc = sl.selected.reserve(max_m)) || (rc = sl.n_aligned.reserve(max_m)) ||
             (rc = sl.status.reserve(max_m)) || (rc = sl.n_char.reserve(max_m)) ||
+            (lead_trail && (rc = sl.lead_trail.reserve(2 * max_m))) ||
             (bits_out && (rc = sl.bits.reserve((size_t)max_m * db->W))))
             return fin(rc);
     }
@@ -1231,6 +1250,8 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         const int64_t span = (a1 - a0 + 15) / 16 * 16;
         PIPE_TRY(hipMemcpyAsync(sl.text.p, text + a0, a1 - a0, hipMemcpyHostToDevice, db->s_up));
         PIPE_TRY(hipMemcpyAsync(sl.offs.p, offs + b0, (m + 1) * sizeof(int64_t), hipMemcpyHostToDevice, db->s_up));
+        if (lead_trail)
+            PIPE_TRY(hipMemcpyAsync(sl.lead_trail.p, lead_trail + 2 * b0, 2 * m * sizeof(int32_t), hipMemcpyHostToDevice, db->s_up));
         PIPE_TRY(hipEventRecord(sl.up, db->s_up));
         // kernels: one compute stream, one workspace (the handle's); results into the slot's own buffers
         PIPE_TRY(hipStreamWaitEvent(db->s_run, sl.up, 0));
@@ -1242,7 +1263,8 @@ int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int6
         o.level_prob = sl.level_prob.p; o.selected = sl.selected.p; o.n_aligned = sl.n_aligned.p; o.status = sl.status.p;
         const char *vbase = (const char *)sl.text.p - a0;      // record i of the sub-batch = vbase[offs[b0 + i] ..)
         if ((rc = encode_dev(db, db->L, vbase, a0 + span, sl.offs.p, m, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
-                             wk.enc_status, wk.win, db->s_run, nullptr, nullptr, /*full_rows=*/bits_out != nullptr)) ||
+                             wk.enc_status, wk.win, db->s_run, nullptr, nullptr, /*full_rows=*/bits_out != nullptr,
+                             lead_trail ? sl.lead_trail.p : nullptr)) ||
             (rc = walk_dev(db, wk, wk.bits, m, wk.enc_status, o, false, db->s_run)))
             return fin(rc);
         PIPE_TRY(hipEventRecord(sl.done, db->s_run));

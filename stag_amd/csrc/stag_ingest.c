@@ -14,9 +14,42 @@ static inline int64_t rstrip_end(const char *buf, int64_t b, int64_t e, int *fal
     return e;
 }
 
+/* bytes of buf[b, e) before the first one that is not '-' */
+static inline int64_t gap_run(const char *buf, int64_t b, int64_t e) {
+    int64_t k = b;
+    while (k + 8 <= e) {
+        uint64_t w;
+        memcpy(&w, buf + k, 8);
+        if (w != 0x2d2d2d2d2d2d2d2dull) break;
+        k += 8;
+    }
+    while (k < e && buf[k] == '-') ++k;
+    return k - b;
+}
+
+/* bytes at the end of text[b, e) that are '-' */
+static inline int64_t gap_run_back(const char *text, int64_t b, int64_t e) {
+    int64_t k = e;
+    while (k - 8 >= b) {
+        uint64_t w;
+        memcpy(&w, text + k - 8, 8);
+        if (w != 0x2d2d2d2d2d2d2d2dull) break;
+        k -= 8;
+    }
+    while (k > b && text[k - 1] == '-') --k;
+    return e - k;
+}
+
 int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_start, int64_t max_records,
                         char *text_out, int64_t text_cap, int64_t text_used_in, int64_t *offs,
                         stag_record_t *recs, int64_t *consumed, int64_t *text_used) {
+    return stag_fasta_scan_trim(buf, len, final, at_start, max_records, text_out, text_cap, text_used_in, offs, recs,
+                                consumed, text_used, NULL);
+}
+
+int64_t stag_fasta_scan_trim(const char *buf, int64_t len, int32_t final, int32_t at_start, int64_t max_records,
+                             char *text_out, int64_t text_cap, int64_t text_used_in, int64_t *offs,
+                             stag_record_t *recs, int64_t *consumed, int64_t *text_used, int32_t *lead_trail) {
     if (!buf || len < 0 || max_records < 0 || !text_out || !offs || !recs || !consumed || !text_used ||
         text_used_in < 0 || text_cap - text_used_in < len)
         return -1;
@@ -26,7 +59,18 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
     if (max_records == 0) { *text_used = used; return 0; }   /* no room for a record: nothing is consumed */
     /* the open record */
     int open = 0, fb = 0;
-    int64_t r_begin = 0, r_id = 0, r_idlen = -1, r_lines = 0, r_text = used;
+    int64_t r_begin = 0, r_id = 0, r_idlen = -1, r_lines = 0, r_text = used, r_lead = 0;
+    /* closes the open record's text: with lead_trail, the run of '-' at its end is dropped and both runs are
+     * reported (a flagged record is re-parsed by the caller, who then reports none dropped) */
+#define STAG_CLOSE_TRIM()                                                        \
+    do {                                                                         \
+        if (lead_trail) {                                                        \
+            const int64_t t_ = gap_run_back(text_out, r_text, used);             \
+            used -= t_;                                                          \
+            lead_trail[2 * n] = (int32_t)(r_lead > 0x7fffffff ? 0x7fffffff : r_lead); \
+            lead_trail[2 * n + 1] = (int32_t)(t_ > 0x7fffffff ? 0x7fffffff : t_);     \
+        }                                                                        \
+    } while (0)
 
     while (pos < len) {
         const char *nl = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
@@ -36,6 +80,7 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
         if (buf[pos] == '>') {
             if (open) {   /* the previous record ends where this header begins */
                 if (r_lines > 0 || fb) {   /* a flagged header may hide lines behind a '\r' */
+                    STAG_CLOSE_TRIM();
                     recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = pos;
                     recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
                     offs[++n] = used;
@@ -55,28 +100,34 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
                 if (memchr(buf + pos, '\r', (size_t)(lim - pos))) fb = 1;
             }
             open = 1;
-            r_begin = pos; r_id = pos + 1; r_idlen = e - (pos + 1); r_lines = 0; r_text = used;
+            r_begin = pos; r_id = pos + 1; r_idlen = e - (pos + 1); r_lines = 0; r_text = used; r_lead = 0;
         } else {
             if (!open) {
                 if (!at_start || *consumed != 0 || n != 0) return -1;   /* every later chunk starts at a header */
                 open = 1; fb = 0;
-                r_begin = pos; r_id = pos; r_idlen = -1; r_lines = 0; r_text = used;
+                r_begin = pos; r_id = pos; r_idlen = -1; r_lines = 0; r_text = used; r_lead = 0;
             }
             const int64_t e = rstrip_end(buf, pos, line_end, &fb);
             unsigned char hi = 0;   /* a non-ASCII character is ONE column for the reference, not one per byte */
-            memcpy(text_out + used, buf + pos, (size_t)(e - pos));
-            for (int64_t i = pos; i < e; ++i) {   /* vectorised by the compiler */
+            int64_t from = pos;
+            if (lead_trail && used == r_text) {   /* nothing but '-' so far: this line's run of them is dropped too */
+                from += gap_run(buf, pos, e);
+                r_lead += from - pos;
+            }
+            memcpy(text_out + used, buf + from, (size_t)(e - from));
+            for (int64_t i = from; i < e; ++i) {   /* vectorised by the compiler */
                 const unsigned char c = (unsigned char)buf[i];
                 hi |= (unsigned char)(c | (c == '\r' ? 0x80 : 0));
             }
             if (hi & 0x80) fb = 1;   /* also an inner '\r': a line break for text-mode readers */
-            used += e - pos;
+            used += e - from;
             ++r_lines;
         }
         pos = next;
     }
     if (final && pos >= len && open) {
         if ((r_lines > 0 || fb) && n < max_records) {
+            STAG_CLOSE_TRIM();
             recs[n].id_begin = r_id; recs[n].id_len = r_idlen; recs[n].raw_begin = r_begin; recs[n].raw_end = len;
             recs[n].n_fields = r_lines; recs[n].flag = fb ? STAG_INGEST_FALLBACK : STAG_INGEST_OK; recs[n].pad = 0;
             offs[++n] = used;
@@ -93,6 +144,7 @@ int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_
     if (final && !open && pos >= len) *consumed = len;
     *text_used = used;
     return n;
+#undef STAG_CLOSE_TRIM
 }
 
 int64_t stag_onehot_parse(const char *buf, int64_t len, int32_t final, int32_t n_features, int32_t words_per_row,
@@ -221,6 +273,27 @@ int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, 
             *o++ = (char)('0' + ((row[f >> 5] >> (f & 31)) & 1u));
             if (f + 1 < n_features) *o++ = '\t';
         }
+        *o++ = '\n';
+    }
+    return (int64_t)(o - out);
+}
+
+int64_t stag_rows_format_short(const char *id_buf, const int64_t *id_begin, const int64_t *id_len, const int32_t *key,
+                               int64_t n, const char *str_blob, const int64_t *str_off, char *out, int64_t out_cap) {
+    if (!id_buf || !id_begin || !id_len || !key || n < 0 || !str_blob || !str_off || (!out && out_cap > 0)) return -1;
+    int64_t need = 0;
+    for (int64_t i = 0; i < n; ++i)
+        if (key[i] >= 0) need += id_len[i] + 1 + (str_off[key[i] + 1] - str_off[key[i]]) + 1;
+    if (need > out_cap) return -need - 1;
+    char *o = out;
+    for (int64_t i = 0; i < n; ++i) {
+        if (key[i] < 0) continue;
+        memcpy(o, id_buf + id_begin[i], (size_t)id_len[i]);
+        o += id_len[i];
+        *o++ = '\t';
+        const int64_t a = str_off[key[i]], b = str_off[key[i] + 1];
+        memcpy(o, str_blob + a, (size_t)(b - a));
+        o += b - a;
         *o++ = '\n';
     }
     return (int64_t)(o - out);

@@ -119,27 +119,25 @@ __device__ __forceinline__ const T STAG_CONST *as_const(const T *p) {
     return (const T STAG_CONST *)(uintptr_t)p;
 }
 
-struct Task {       // 128 bytes; a walk kernel reads the first 32 and its own 32 with two scalar loads
+struct Task {       // 64 bytes: the gather walk reads the first 32 with one scalar load, the matrix-core walk both halves
     int32_t node, count;
     int32_t c0, k;                     // children of node: ids c0 .. c0+k-1, k >= 2 (other nodes get no task)
     // HINT: everything a walk kernel would otherwise have to look up -- in loads that depend on each other -- before
     // it can fetch coefficients, for the window [hA, hB) (chunks) of the task's first sequence.  The grouping kernel
     // looks it up, where a million threads hide those loads; the walk then issues all its fetches right after this
     // record arrives.  Tasks are mostly made of rows with the same window (amplicon reads); when the union of the
-    // task's windows differs, the walk does the lookups itself.
+    // task's windows differs, the walk does the lookups itself.  (k_walk_level looks its coefficient ranges up
+    // itself: resolving them here made the grouping slower and the walk no faster.)
     int32_t hA, hB;
     int32_t mfma, pad1;                // mfma: the node has matrix-core tables (k_walk_mfma's task)
-    uint32_t unused[8];                // (k_walk_level looks its coefficient ranges up itself: resolving them here
-                                       // made the grouping slower and the walk no faster)
     // k_walk_mfma: the node's digit matrix and the hint window's union features
     uint64_t dig_at;                   // byte offset in dig of column 0's digit of the window's first feature
     uint32_t U;                        // bytes per column
     uint32_t f0, nf;                   // first union feature of the window (index into pfeat) and their number
     uint32_t pad2;
     double qscale;
-    int32_t pad3[8];
 };
-static_assert(sizeof(Task) == 128, "two aligned scalar loads per kernel");
+static_assert(sizeof(Task) == 64, "two aligned 32-byte scalar loads");
 // order[]: a sequence id and its R0 window, so the walk needs one load, not two.  Task t owns the
 // 64 slots order[64 t .. 64 t + 63] (the first `count` are filled): the walk can fetch its task
 // record and its sequences at the same time instead of one after the other.
@@ -199,7 +197,7 @@ __device__ __forceinline__ uint32_t byte_mask(uint32_t h80) { return (h80 << 1) 
 
 // keep[lo_cut * 17 + hi_cut]: byte mask (4 dwords) of the bytes [lo_cut, hi_cut) of a 16-byte vector --
 // the part of a record's first / last vector that belongs to the record.
-struct KeepLut {
+struct alignas(16) KeepLut {      // (read with 16-byte loads)
     uint32_t m[17 * 17][4];
 };
 constexpr KeepLut make_keep_lut() {
@@ -269,9 +267,13 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
                                                     int32_t *__restrict__ status_out,
                                                     uint32_t *__restrict__ win_out,
                                                     const int64_t *__restrict__ ends,
-                                                    const int32_t *__restrict__ pre_status) {
+                                                    const int32_t *__restrict__ pre_status,
+                                                    const int32_t *__restrict__ lead_trail) {
     // ends (may be null): record i is text[offs[i] .. ends[i]) instead of [offs[i] .. offs[i+1]);
-    // pre_status (may be null): a non-zero entry is the record's final status (back-translation failed)
+    // pre_status (may be null): a non-zero entry is the record's final status (back-translation failed);
+    // lead_trail (may be null): record i's text is its aligned string WITHOUT a run of lead_trail[2 i] '-' columns
+    // at its start and lead_trail[2 i + 1] at its end (the host scanner drops them: a gap column is what the row
+    // already says, so it only moves the column count)
     extern __shared__ uint32_t s_enc[];  // one W-word row per record of the workgroup
     constexpr int RPW = 64 / G;          // records per wave
     const int lane = threadIdx.x & 63;
@@ -292,7 +294,11 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
     begin = max(begin, (int64_t)0);
     end = max(min(end, text_bytes), begin);
     const int64_t base = begin & ~(int64_t)15;
-    int running = 0, aligned = 0;
+    int running = 0, aligned = 0, trail = 0;
+    if (live && lead_trail) {
+        running = max(RD(lead_trail, 2 * seq), 0);
+        trail = max(RD(lead_trail, 2 * seq + 1), 0);
+    }
     // Positions inside the loop are 32-bit and relative to the record's first byte (a record is
     // shorter than 2 GB); only the load address is 64-bit.
     const int len = (int)(end - begin);
@@ -448,6 +454,7 @@ __global__ __launch_bounds__(256) void k_encode_a2m(const uint8_t *__restrict__ 
         step(wb, kb, wa, ka, rel0);
         rel0 += STEP;
     }
+    running += trail;
     // totals over the record's lanes: valid in the group's last lane, which writes the record's scalars
     aligned = group_reduce_last<G>(aligned, 0, [](int x, int y) { return x + y; });
     uint32_t *dst = rows + (size_t)(live ? seq : 0) * W;
@@ -907,8 +914,6 @@ struct HintTables {
 __device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint32_t win, const HintTables &h) {
     Task tk;
     tk.node = nd; tk.count = count; tk.c0 = c0; tk.k = k; tk.pad1 = 0; tk.pad2 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) tk.pad3[i] = 0;
     const int l4 = (int)(win & 0xffffu), h4 = (int)(win >> 16);
     int hA = 0, hB = 0;
     if (h4 > l4) { hA = l4 >> 2; hB = min((h4 + 3) >> 2, h.NC); }
@@ -916,8 +921,6 @@ __device__ __forceinline__ Task make_task(int nd, int count, int c0, int k, uint
     const bool mfma = h.mfma_ok && RD(h.mfma_ok, nd);
     tk.mfma = mfma ? 1 : 0;
     tk.dig_at = 0; tk.U = 0; tk.f0 = 0; tk.nf = 0; tk.qscale = 0.0;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) tk.unused[j] = 0;
     if (mfma) {
         const uint32_t *po = h.pf_off + (size_t)nd * h.NC;
         const uint32_t first = RD(po, 0), f0 = RD(po, hA), f1 = RD(po, hB);
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
 
     const int lane = threadIdx.x & 63;
     const int n_tasks = RDC(a.n_tasks, 0);
-    const i32x8 tk = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x);
+    const i32x8 tk = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 2 * blockIdx.x);
     // the task's slots of order[] sit at a fixed place: fetched together with the task record
     // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
     SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);
@@ -1413,8 +1416,8 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
     unsigned long long stamp_ = __builtin_readcyclecounter();
 #endif
     const int n_tasks = RDC(a.n_tasks, 0);
-    const i32x8 t0 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x);
-    const i32x8 t2 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 4 * blockIdx.x + 2);
+    const i32x8 t0 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 2 * blockIdx.x);
+    const i32x8 t2 = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 2 * blockIdx.x + 1);
     SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);     // lane = row of the task (staging, X)
     if ((int)blockIdx.x >= n_tasks) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -179,14 +179,19 @@ class Database:
         text, offs = pack_text(strings)
         return self.classify_a2m_text(text, offs, min_perc_state, want_bits)
 
-    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False):
+    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False, lead_trail=None):
         """Same for records already laid out back to back: record i = text[offs[i]:offs[i+1]]
-        (uint8, int64[n+1]); what stag_amd.ingest.fasta_batches produces."""
+        (uint8, int64[n+1]); what stag_amd.ingest.fasta_batches produces.  lead_trail (int32 [n, 2], optional):
+        the '-' columns dropped from either end of each record (fasta_batches(trim=True))."""
         text = np.ascontiguousarray(text, dtype=np.uint8)
         offs = np.ascontiguousarray(offs, dtype=np.int64)
         n = len(offs) - 1
         if n < 0 or (n > 0 and (offs[0] < 0 or offs[-1] > len(text))):
             raise ValueError("offs does not describe records inside text")
+        if lead_trail is not None:
+            lead_trail = np.ascontiguousarray(lead_trail, dtype=np.int32)
+            if lead_trail.size != 2 * n:
+                raise ValueError("lead_trail must hold two counts per record")
         if len(text) == 0:
             text = np.zeros(16, dtype=np.uint8)
         res = BatchResult(n, self.max_depth, self.n_keys)
@@ -194,8 +199,9 @@ class Database:
         res.n_char = np.zeros(n, dtype=np.int32)
         if want_bits:
             res.bits = np.zeros((n, self.words_per_row), dtype=np.uint32)
-        _lib.check(_lib.lib().stag_classify_a2m(self.handle, _lib.ptr(text), _lib.ptr(offs), n, float(min_perc_state),
-                                                ctypes.byref(st), _lib.ptr(res.bits), _lib.ptr(res.n_char)))
+        _lib.check(_lib.lib().stag_classify_a2m_trimmed(self.handle, _lib.ptr(text), _lib.ptr(offs), _lib.ptr(lead_trail), n,
+                                                        float(min_perc_state), ctypes.byref(st), _lib.ptr(res.bits),
+                                                        _lib.ptr(res.n_char)))
         res.level_prob = res.level_prob[:, :self.n_keys]
         return res
 

@@ -36,11 +36,14 @@ RECORD = np.dtype([("id_begin", "<i8"), ("id_len", "<i8"), ("raw_begin", "<i8"),
 EXPORTS = {
     "stag_fasta_scan": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
                                          c_p, ctypes.c_int64, ctypes.c_int64, c_p, c_p, c_p, c_p]),
+    "stag_fasta_scan_trim": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int64,
+                                              c_p, ctypes.c_int64, ctypes.c_int64, c_p, c_p, c_p, c_p, c_p]),
     "stag_onehot_parse": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                                            ctypes.c_int64, c_p, c_p, c_p]),
     "stag_onehot_lines": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, c_p, c_p, c_p, c_p]),
     "stag_onehot_format": (ctypes.c_int64, [c_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int32, c_p, c_p, c_p,
                                             ctypes.c_int64]),
+    "stag_rows_format_short": (ctypes.c_int64, [c_p, c_p, c_p, c_p, ctypes.c_int64, c_p, c_p, c_p, ctypes.c_int64]),
 }
 _lib = None
 
@@ -113,7 +116,7 @@ class _TextRing:
 
 
 def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start=1, text_mode=False, pinned=False,
-                  ring_slots=2):
+                  ring_slots=2, trim=False):
     """Yields (ids, text, offs): ids a list of str, record i's sequence = text[offs[i]:offs[i+1]]
     (uint8 array padded to a multiple of 16 bytes, int64 offsets).  `stream` is a binary file object
     (a pipe's stdout).  Same records, ids and strings as read_fasta(stream, head_start=1); with
@@ -121,9 +124,13 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
     ends a line (the gene file of align.py:150).  batch_records is a target, not a bound: records
     that had to be re-parsed the slow way are all added to the batch that was being filled.
     pinned: the text arrays are views of ring_slots page-locked buffers used in turn (a batch stays valid until
-    ring_slots - 1 further batches have been produced)."""
+    ring_slots - 1 further batches have been produced).
+    trim: yields (ids, text, offs, lead_trail) instead -- each record without the run of '-' at its start and at
+    its end, lead_trail int32 [n, 2] = how many were dropped (what Database.classify_a2m_text(lead_trail=...) and
+    stag_classify_a2m_trimmed take: a gap column is what a row says anyway, so it need not travel to the GPU)."""
     L = lib()
     ring = _TextRing(ring_slots) if pinned else None
+    lt_parts = []
     buf = bytearray(max(chunk_bytes, 1))     # read buffer: [0, have) holds unparsed bytes
     scratch = np.empty(len(buf), dtype=np.uint8)
     have, at_start, ended = 0, True, False
@@ -141,6 +148,9 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
             text[at:at + len(t)] = t
             at += len(t)
         out = (ids, text, np.concatenate(offs_parts))
+        if trim:
+            out += (np.concatenate(lt_parts).reshape(-1, 2) if lt_parts else np.zeros((0, 2), dtype=np.int32),)
+            lt_parts.clear()
         ids, texts, offs_parts, total = [], [], [np.zeros(1, dtype=np.int64)], 0
         return out
 
@@ -155,9 +165,10 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
             offs = np.zeros(room + 1, dtype=np.int64)
             recs = np.zeros(max(room, 1), dtype=RECORD)
             consumed, used = ctypes.c_int64(0), ctypes.c_int64(0)
-            n = L.stag_fasta_scan(_ptr(view) if len(view) else _ptr(scratch), len(view), int(ended), int(at_start), room,
-                                  _ptr(scratch), len(scratch), 0, _ptr(offs), _ptr(recs), ctypes.byref(consumed),
-                                  ctypes.byref(used))
+            lt = np.zeros(2 * max(room, 1), dtype=np.int32) if trim else None
+            n = L.stag_fasta_scan_trim(_ptr(view) if len(view) else _ptr(scratch), len(view), int(ended), int(at_start),
+                                       room, _ptr(scratch), len(scratch), 0, _ptr(offs), _ptr(recs), ctypes.byref(consumed),
+                                       ctypes.byref(used), _ptr(lt) if trim else None)
             if n < 0:
                 raise ValueError("malformed FASTA/A2M stream (a record does not start with '>')")
             recs = recs[:n]
@@ -174,6 +185,8 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
                 texts.append(t[:int(o[-1])].copy())
                 offs_parts.append(o[1:] + total)
                 total += int(o[-1])
+                if trim:
+                    lt_parts.append(np.zeros(2 * len(pairs), dtype=np.int32))
             elif n:
                 begins = (recs["id_begin"] + (pos - 1 + head_start)).tolist()
                 ends = (recs["id_begin"] + recs["id_len"] + pos).tolist()
@@ -182,6 +195,8 @@ def fasta_batches(stream, batch_records=1 << 16, chunk_bytes=1 << 26, head_start
                 texts.append(scratch[:used.value].copy())
                 offs_parts.append(offs[1:n + 1] + total)
                 total += used.value
+                if trim:
+                    lt_parts.append(lt[:2 * n])
             if consumed.value:
                 at_start = False
             pos += consumed.value

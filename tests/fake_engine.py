@@ -42,8 +42,10 @@ class OracleDatabase(Database):
             res.status[bad] = np.asarray(status_in)[bad]
         return res
 
-    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False):
+    def classify_a2m_text(self, text, offs, min_perc_state=0.0, want_bits=False, lead_trail=None):
         strings = [bytes(text[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(len(offs) - 1)]
+        if lead_trail is not None:      # the records came without their flanking gap columns
+            strings = ["-" * int(a) + s + "-" * int(b) for s, (a, b) in zip(strings, np.asarray(lead_trail).reshape(-1, 2))]
         return self.classify_a2m(strings, min_perc_state, want_bits)
 
     def classify_concat(self, gene_len, gene_rows, src_row, want_bits=False):

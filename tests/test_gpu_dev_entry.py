@@ -294,3 +294,50 @@ def test_host_pipeline_sub_batches_pinned_and_pageable(monkeypatch):
         bad = offs.copy()
         bad[0] = -16
         assert _lib.lib().stag_classify_a2m(db.handle, _lib.ptr(text), _lib.ptr(bad), n, 0.0, ctypes.byref(st), None, None) == -1
+
+
+def test_trimmed_text_entry_equals_the_full_text_entry():
+    """stag_classify_a2m_trimmed: records without their flanking '-' runs + the two counts give, field for field and
+    bit for bit, what stag_classify_a2m gives for the whole strings (align.py:37-58: a '-' column is the row's
+    default) -- packed rows, n_char and the filter included; also across sub-batches of the host pipeline."""
+    import io
+    import os
+    from stag_amd import ingest
+    rng = np.random.default_rng(21)
+    ncol = 420
+    L = 5 * ncol
+    from test_gpu_parity import random_db
+    taxonomy, tax_function, classifiers = random_db(rng, ncol, [[4], [2, 5], [1, 3]], 0.1)
+    strings = []
+    for i in range(700):
+        s = np.full(ncol, "-", dtype="<U1")
+        a, b = sorted(rng.integers(0, ncol + 1, size=2))
+        if i % 9:
+            s[a:b] = rng.choice(list("ACGT-N"), size=b - a, p=[0.22, 0.22, 0.22, 0.22, 0.08, 0.04])
+        s = list(s)
+        for _ in range(int(rng.integers(0, 3))):
+            s.insert(int(rng.integers(0, len(s) + 1)), str(rng.choice(list("acgt"))))
+        if i % 50 == 3:
+            s = s[:-2]                       # wrong length
+        strings.append("".join(s))
+    strings[5] = "-" * ncol
+    strings[6] = "acgt"
+    stream = "".join(">r%d\n%s\n" % (i, s) for i, s in enumerate(strings)).encode()
+    (ids, text, offs, lt), = list(ingest.fasta_batches(io.BytesIO(stream), trim=True))
+    assert int(offs[-1]) < sum(map(len, strings)) // 2
+    with Database.from_dicts(taxonomy, tax_function, classifiers, n_features=L) as db:
+        for pipe in (None, "97"):
+            if pipe:
+                os.environ["STAG_PIPE_RECORDS"] = pipe
+            try:
+                for want_bits in (True, False):
+                    full = db.classify_a2m(strings, min_perc_state=20.0, want_bits=want_bits)
+                    trimmed = db.classify_a2m_text(text, offs, min_perc_state=20.0, want_bits=want_bits, lead_trail=lt)
+                    for f in ("status", "n_char", "n_aligned", "path_len", "path_node", "path_prob", "selected",
+                              "level_prob", "n_lead_single"):
+                        assert np.array_equal(getattr(trimmed, f), getattr(full, f)), (f, pipe, want_bits)
+                    if want_bits:
+                        assert np.array_equal(trimmed.bits, full.bits)
+            finally:
+                os.environ.pop("STAG_PIPE_RECORDS", None)
+        assert set(np.unique(full.status)) >= {0, 5, 6, 7}

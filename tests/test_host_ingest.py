@@ -364,3 +364,36 @@ def test_onehot_line_finder_lines_far_longer_than_the_search_window(tmp_path):
     assert [g[0] for g in got] == ["g%d" % i for i in range(9)] and all(g[1] == body for g in got)
     with pytest.raises(ValueError):
         lines_of(str(path), 1 << 18)
+
+
+@pytest.mark.parametrize("batch_records,chunk_bytes", [(1 << 16, 1 << 26), (97, 1000), (5, 333), (1, 64)])
+def test_trimmed_records_put_back_together_are_the_records(batch_records, chunk_bytes):
+    """fasta_batches(trim=True): each record without the run of '-' at its start and its end, and the two counts;
+    '-' * lead + text + '-' * trail is the record read_fasta gives, whatever the chunk and batch sizes: all-gap
+    records, records without gaps, wrapped lines whose breaks fall inside the runs, empty covered stretches."""
+    rng = np.random.default_rng(11)
+    recs = []
+    for i in range(1200):
+        ncol = int(rng.integers(1, 300))
+        s = np.full(ncol, "-", dtype="<U1")
+        a, b = sorted(rng.integers(0, ncol + 1, size=2))
+        if i % 7:
+            s[a:b] = rng.choice(list("ACGT-Nacg."), size=b - a)
+        recs.append("".join(s))
+    width = [60, 7, 1000][batch_records % 3]
+    stream = "".join(">id%d x y\n%s\n" % (i, "\n".join(r[j:j + width] for j in range(0, len(r), width)))
+                     for i, r in enumerate(recs)).encode()
+    ids, got, dropped = [], [], 0
+    for bids, text, offs, lt in ingest.fasta_batches(io.BytesIO(stream), batch_records=batch_records,
+                                                     chunk_bytes=chunk_bytes, trim=True):
+        assert lt.shape == (len(bids), 2) and lt.dtype == np.int32 and len(text) % 16 == 0
+        for i in range(len(bids)):
+            body = bytes(text[offs[i]:offs[i + 1]]).decode()
+            assert not body.startswith("-") and not body.endswith("-")
+            got.append("-" * int(lt[i, 0]) + body + "-" * int(lt[i, 1]))
+            dropped += int(lt[i].sum())
+        ids += bids
+    assert got == recs and ids == ["id%d x y" % i for i in range(len(recs))]
+    assert dropped > sum(map(len, recs)) // 3
+    plain = records_of(ingest.fasta_batches(io.BytesIO(stream), batch_records=batch_records, chunk_bytes=chunk_bytes))
+    assert [r[1] for r in plain] == recs
