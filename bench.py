@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")
 
 
 def _load_traffic():
@@ -68,6 +68,8 @@ def main():
                     help="c2 is the bench line (BASELINE.json configs[1]); c3 / c5 reproduce the other shapes")
     ap.add_argument("--host-steps", type=int, default=3, help="timed host-to-host steps (0: skip that leg)")
     ap.add_argument("--onehot-lines", type=int, default=65536, help="lines of the -s reader leg (0: skip it)")
+    ap.add_argument("--a2m-reads", type=int, default=1_000_000, help="reads of the A2M-file leg (0: skip it)")
+    ap.add_argument("--threads", type=int, default=0, help="scanner threads of the A2M-file leg (0: the job's cores, at most 16)")
     args = ap.parse_args()
     if args.reads == 1_000_000 and args.db_scale == 1.0 and args.workload == "c2":
         TRAFFIC.update(_load_traffic())
@@ -144,10 +146,11 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dt_min = dt
+    if world > 1:     # the job's time is the slowest rank's; the fastest rank's is kept beside it to show skew
+        tt = torch.tensor([dt, -dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt, dt_min = float(tt[0].item()), -float(tt[1].item())
 
     # per-kernel device time (HIP events on the launch stream, recorded inside the library)
     prof_steps = max(1, min(args.steps, 5))
@@ -193,6 +196,104 @@ def main():
                     "how": "stag_classify_a2m on page-locked host buffers (stag_host_alloc): sub-batches of 65,536 reads, "
                            "text up / kernels / results down on three streams"}
         del h_text, h_offs, h_out
+
+    # ---- the whole host side, measured: an A2M file (what `hmmalign | esl-reformat a2m -` writes: records wrapped
+    # at 60 columns) in the page cache -> scanned by a pool of threads into trimmed records in page-locked buffers
+    # (stag_amd.stream) -> GPU (stag_classify_a2m_trimmed) -> the reference's two-column output lines in a file.
+    # And, from the same scan, SURVEY 8(d)'s boundary once more for the trimmed form the scanner hands over.
+    a2m_leg = None
+    if args.a2m_reads > 0 and world == 1:
+        import tempfile
+        from stag_amd import parallel, stream
+        m = min(args.a2m_reads, n)
+        lens = (offs[1:m + 1] - offs[:m]).astype(np.int64)
+        a2m = tempfile.NamedTemporaryFile(suffix=".a2m", delete=False)
+        order = []                                      # read index of every record of the file, in file order
+        with a2m:
+            for ln in np.unique(lens).tolist():         # (reads of one length wrap the same way: whole blocks at a time)
+                idx = np.flatnonzero(lens == ln)
+                for c0 in range(0, len(idx), 50_000):
+                    part = idx[c0:c0 + 50_000]
+                    body = text[(offs[part][:, None] + np.arange(ln)[None, :]).ravel()].reshape(len(part), ln)
+                    head = np.frombuffer("".join(">read%08d\n" % i for i in part.tolist()).encode(), np.uint8).reshape(len(part), 14)
+                    cols = [head]
+                    for c in range(0, ln, 60):
+                        cols += [body[:, c:c + 60], np.full((len(part), 1), 10, np.uint8)]
+                    a2m.write(np.concatenate(cols, axis=1).tobytes())
+                    order.append(part)
+        order = np.concatenate(order)
+        size = os.path.getsize(a2m.name)
+        threads = args.threads or stream.default_threads()
+        pool = parallel.DevicePool(lambda d_: db, [local], own=False)
+        tsv = a2m.name + ".tsv"
+        try:
+            stream.classify_a2m_file(pool, a2m.name, output=tsv, threads=threads)        # warm: page cache, buffers
+            a0 = time.perf_counter()
+            alen, n_lines = stream.classify_a2m_file(pool, a2m.name, output=tsv, threads=threads)
+            adt = time.perf_counter() - a0
+            # the scan alone (all threads, nothing else)
+            s0 = time.perf_counter()
+            batches = [(b.text.copy(), b.offs, b.lead_trail) for b in stream.a2m_file_batches(a2m.name, threads=threads)]
+            sdt = time.perf_counter() - s0
+        finally:
+            pool.close()
+        # the lines are what the per-row formatter gives for the device-resident results of the same reads
+        names = np.array(t.names, dtype=object)
+        sel = out["selected"].cpu().numpy()
+        pn = out["path_node"].cpu().numpy()
+        want = {}
+        for i in order[:2000].tolist() + order[-2000:].tolist():
+            keep_to = int(db.keys[sel[i]]) + 1 if sel[i] >= 0 else 0
+            want["read%08d" % i] = ";".join(names[pn[i, :keep_to]])
+        with open(tsv) as fh:
+            got_lines = fh.read().splitlines()
+        got = dict(l.split("\t") for l in got_lines[1:] if l.split("\t")[0] in want)
+        os.remove(tsv)
+        os.remove(a2m.name)
+        # the trimmed form through the pipelined host entry point, from page-locked buffers
+        tt_text = np.concatenate([b[0][:int(b[1][-1])] for b in batches])
+        tt_offs = np.concatenate([[0]] + [b[1][1:] + o for b, o in zip(batches, np.cumsum([0] + [int(b[1][-1]) for b in batches[:-1]]))])
+        tt_lt = np.concatenate([b[2] for b in batches])
+        del batches
+        p_text = _lib.PinnedArray(len(tt_text) + 16, np.uint8)
+        p_text.a[:len(tt_text)] = tt_text
+        p_offs = _lib.PinnedArray(len(tt_offs), np.int64)
+        p_offs.a[:] = tt_offs
+        p_lt = _lib.PinnedArray(tt_lt.shape, np.int32)
+        p_lt.a[:] = tt_lt
+        t_out = {"path_node": _lib.PinnedArray((m, D), np.int32), "path_prob": _lib.PinnedArray((m, D), np.float64),
+                 "path_len": _lib.PinnedArray(m, np.int32), "n_lead_single": _lib.PinnedArray(m, np.int32),
+                 "level_prob": _lib.PinnedArray((m, K), np.float64), "selected": _lib.PinnedArray(m, np.int32),
+                 "n_aligned": _lib.PinnedArray(m, np.int32), "status": _lib.PinnedArray(m, np.int32)}
+        t_res = _lib.Results()
+        for f, _ in _lib.Results._fields_:
+            setattr(t_res, f, _lib.ptr(t_out[f].a))
+
+        def trimmed_step():
+            _lib.check(lib.stag_classify_a2m_trimmed(db.handle, _lib.ptr(p_text.a), _lib.ptr(p_offs.a), _lib.ptr(p_lt.a), m, 0.0,
+                                                     ctypes.byref(t_res), None, None))
+
+        trimmed_step()
+        h0 = time.perf_counter()
+        for _ in range(max(args.host_steps, 1)):
+            trimmed_step()
+        tdt = (time.perf_counter() - h0) / max(args.host_steps, 1)
+        same = all(np.array_equal(t_out[f].a, out[f][:m].cpu().numpy()[order]) for f in t_out)
+        up = float(tt_offs[-1]) + 16.0 * m
+        a2m_leg = {"value": round(m / adt, 1), "unit": "seqs/s", "reads": m, "threads": threads, "file_bytes": int(size),
+                   "text_GBs": round(size / adt / 1e9, 2), "lines_written": int(n_lines),
+                   "lines_equal_device_resident_results": bool(got == want and len(got) == len(want)),
+                   "scan_only": {"value": round(m / sdt, 1), "text_GBs": round(size / sdt / 1e9, 2)},
+                   "how": "stream.classify_a2m_file: A2M file (60 columns per line) in the page cache, chunks scanned by %d "
+                          "threads (stag_fasta_scan_trim) into page-locked buffers, stag_classify_a2m_trimmed, two-column "
+                          "lines put together in C (stag_rows_format_short), output file written" % threads,
+                   "host_to_host_trimmed": {
+                       "value": round(m / tdt, 1), "unit": "seqs/s", "ms_per_step": round(tdt * 1e3, 3),
+                       "h2d_bytes": int(up), "bytes_per_read_up": round(up / m, 1),
+                       "equals_device_resident_results": bool(same),
+                       "how": "stag_classify_a2m_trimmed on the scanner's output in page-locked memory (records without "
+                              "their flanking gap columns + two counts each) -> result arrays in page-locked memory"}}
+        del p_text, p_offs, p_lt, t_out, tt_text
 
     # ---- the -s reader (classify.py:16-20) on the GPU, measured: a file of one-hot lines (what -S writes: 2 bytes
     # per feature) -> lines found on the host -> fields parsed by k_parse_onehot -> walk -> host results
@@ -356,13 +457,14 @@ def main():
     print(json.dumps({
         "metric": "classified seqs/sec post-hmmalign", "value": round(value, 1), "unit": "seqs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 4), "ms_per_step_fastest_rank": round(dt_min / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": WORKLOADS[args.workload],
                    "reads_per_gpu": n, "ncol": ncol, "L": t.n_features, "depth": D, "n_nodes": t.n_nodes,
                    "nnz_coefficients": t.nnz, "table_bytes": db.table_bytes, "classified_ok": n_ok,
                    "sharding": "reads split across ranks, tables replicated, no collective"},
-        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_c, "host_to_host": host_leg, "onehot_text": onehot_leg,
+        "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_c, "host_to_host": host_leg, "a2m_file": a2m_leg, "onehot_text": onehot_leg,
         "parity": parity,
     }))
     if world > 1:

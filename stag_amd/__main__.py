@@ -24,6 +24,7 @@ def print_menu_classify():
                      "  -d  FILE  database created with create_db or train\n"
                      "  -i  FILE  sequences to taxonomically annotate (fasta format)\n"
                      "  -s  FILE  aligned sequences, can be provided instead of -i\n"
+                     "  --a2m FILE  (this build) the aligner's A2M output kept on disk, instead of -i: scanned by all cores\n"
                      "  -p  FILE  protein sequences, corresponding to -i\n"
                      "  -S  FILE  save intermediate alignment file\n"
                      "  -o  FILE  output file name [stdout]\n"
@@ -68,6 +69,7 @@ def _main(argv=None):
             parser.add_argument(flag, dest=dest, action="store_true")
         else:
             parser.add_argument(flag, dest=dest, type=kind, default=None)
+    parser.add_argument("--a2m", dest="aligned_a2m", type=str, default=None)      # this build's own flag
     parser.add_argument("-t", dest="threads", type=int, default=1)
     parser.add_argument("-v", dest="verbose", type=int, default=3, choices=[1, 2, 3, 4])
     parser.add_argument("--version", action="version",
@@ -84,7 +86,7 @@ def _main(argv=None):
 
     error = ""
     if args.command == 'classify':
-        if not args.fasta_input and not args.aligned_sequences:
+        if not args.fasta_input and not args.aligned_sequences and not args.aligned_a2m:
             error = "missing <fasta_seqs> (-i) or <aligned_seq> (-s)"
         elif not args.database:
             error = "missing <database> (-d)"
@@ -98,6 +100,11 @@ def _main(argv=None):
         if args.intermediate_al and os.path.isfile(args.intermediate_al):
             os.remove(args.intermediate_al)
         from . import classify
+        if args.aligned_a2m:
+            check_file_exists(args.aligned_a2m, isfasta=True)
+            classify.classify_a2m(args.database, args.aligned_a2m, output=args.output, long_out=args.long_out,
+                                  verbose=args.verbose, min_perc_state=args.min_perc_state)
+            return None
         classify.classify(args.database, fasta_input=args.fasta_input, protein_fasta_input=args.protein_fasta_input,
                           verbose=args.verbose, threads=args.threads, output=args.output, long_out=args.long_out,
                           current_tool_version=tool_version, aligned_sequences=args.aligned_sequences,

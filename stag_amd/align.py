@@ -167,12 +167,18 @@ def aligned_batches(seq_file, protein_file, hmm_file, use_cmalign, n_threads, ve
         genes = ingest.fasta_batches(gene_fh, batch_records=size, text_mode=True)
         prots = ingest.fasta_batches(parse_proc.stdout, batch_records=size)
         P, G = [[], None, None], [[], None, None]
+        p_ended = g_ended = False
         while True:
-            if not P[0] and not take(P, prots):
-                break
-            if not G[0] and not take(G, genes):
-                break                                  # zip() stops with the shorter stream
+            # both sides are topped up to a full batch before a pair of batches is cut: two batchers that cut at
+            # different records would otherwise stay out of phase and every second batch would be a handful of
+            # records that still pays for a whole chain of launches
+            while not p_ended and len(P[0]) < size:
+                p_ended = not take(P, prots)
+            while not g_ended and len(G[0]) < size:
+                g_ended = not take(G, genes)
             m = min(len(P[0]), len(G[0]))
+            if m == 0:
+                break                                  # zip() stops with the shorter stream
             clash = next((j for j in range(m) if P[0][j] != G[0][j]), None)
             if clash is not None:
                 # the reference gets this far only if the pairs before it went through (align.py:149-159):

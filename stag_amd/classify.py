@@ -17,7 +17,7 @@ import time
 import numpy as np
 
 from . import __version__ as tool_version
-from . import _lib, align, ingest, parallel, table_cache
+from . import _lib, align, ingest, parallel, stream, table_cache
 from .databases import load_db, open_stagdb
 from .engine import Database, raise_for_status
 from .tables import pack_db
@@ -263,3 +263,85 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                 sys.stderr.write("[E::main] you can find the file here:\n" + outfile.name + "\n")
                 sys.exit(1)
     return state["alignment_length"], list_to_print
+
+
+def classify_a2m(database, a2m_file, output=None, long_out=False, verbose=3, min_perc_state=0, threads=None,
+                 device=None, cache=True):
+    """This build's own entry (no counterpart among the reference's commands; `stag classify --a2m FILE`): the
+    classification path from an alignment that is already on disk -- the A2M text `hmmalign | esl-reformat a2m -`
+    wrote (align.py:127-141), for a protein database the codon alignment -- so that the aligner, which stays the
+    reference's external CPU step, can be run and timed apart from this path.  The file is scanned by a pool of
+    threads (stag_amd.stream), batches go to the GPU(s) of STAG_DEVICES without their flanking gap columns, and
+    the output is classify()'s: same header, same lines, same temp-file-then-move.  Under torchrun every rank
+    scans only its own chunks of the file.  Returns (alignment_length, number of result lines)."""
+    t0 = time.time()
+    cached = table_cache.load(database, None, a2m_file) if cache else None
+    if cached is not None:
+        hmm_file_path, _, tables, _ = cached
+    else:
+        hmm_file_path, _, taxonomy, tax_function, classifiers, _ = load_db(database, aligned_sequences=a2m_file)
+        tables = pack_db(taxonomy, tax_function, classifiers)
+        del classifiers
+    os.remove(hmm_file_path)        # (no aligner runs here)
+    world, rank = parallel.world_rank()
+    devices = [device] if device is not None else (parallel.devices_from_env() if world == 1 else [parallel.local_device()])
+    pool = parallel.DevicePool(lambda d: Database(tables, device=d), devices)
+    if verbose > 2:
+        sys.stderr.write("Load database: " + str("{0:.2f}".format(time.time() - t0)) + " sec\n")
+    t1 = time.time()
+    error, tagged, state = None, [], {"alignment_length": None, "batch": 0}
+    try:
+        if world == 1 and not long_out:
+            # two-column lines straight from the result arrays: no Python object per sequence
+            result = stream.classify_a2m_file(pool, a2m_file, output=output, threads=threads, min_perc_state=min_perc_state)
+            if verbose > 2:
+                sys.stderr.write("Classify sequences: " + str("{0:.2f}".format(time.time() - t1)) + " sec\n")
+            return result
+        db = pool.first
+        pending = collections.deque()
+
+        def finish_oldest():
+            b, batch, fut = pending.popleft()
+            state["batch"] = b
+            res = fut.result()
+            passed = np.flatnonzero(res.status == _lib.SEQ_OK)
+            if len(passed) and not state["alignment_length"]:
+                state["alignment_length"] = 5 * int(res.n_char[passed[0]])
+            tagged.append((b, db.result_rows(res, batch.ids(), long_out=long_out)))
+
+        for b, batch in enumerate(stream.a2m_file_batches(a2m_file, threads=threads, keep=_in_flight(pool) + 2,
+                                                          world=world, rank=rank)):
+            if batch is None or batch.n == 0:
+                continue
+            pending.append((b, batch, pool.submit(lambda d, x=batch: d.classify_a2m_text(
+                x.text, x.offs, min_perc_state=min_perc_state, lead_trail=x.lead_trail))))
+            while len(pending) > _in_flight(pool):
+                finish_oldest()
+        while pending:
+            finish_oldest()
+    except Exception as e:       # re-raised on every rank by gather_in_order
+        error = e
+    finally:
+        pool.close()
+    rows = parallel.gather_in_order(tagged, error, state["batch"])
+    if rank != 0:
+        return state["alignment_length"], 0
+    if verbose > 2:
+        sys.stderr.write("Classify sequences: " + str("{0:.2f}".format(time.time() - t1)) + " sec\n")
+    header = OUT_HEADER if long_out else OUT_HEADER[:2]
+    sink = tempfile.NamedTemporaryFile(delete=False, mode="w") if output else sys.stdout
+    if output:
+        os.chmod(sink.name, 0o644)
+    try:
+        print(*header, sep="\t", file=sink)
+        for line in rows:
+            print(*line, sep="\t", file=sink)
+        sink.flush()
+        if output:
+            os.fsync(sink.fileno())
+    finally:
+        if output:
+            sink.close()
+    if output:
+        shutil.move(sink.name, output)
+    return state["alignment_length"], len(rows)

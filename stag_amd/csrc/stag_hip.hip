@@ -172,6 +172,10 @@ namespace {
 constexpr int MAX_DEVICES = 64;
 std::mutex g_scratch_mu;
 unsigned char *g_scratch_ptr[MAX_DEVICES] = {};
+// the stream of the last stag_classify_a2m_noalloc_dev call per device: a call on ANOTHER stream while that one
+// still has work queued would share the array with it (calls on one stream are ordered and may follow each other)
+hipStream_t g_scratch_stream[MAX_DEVICES] = {};
+bool g_scratch_used[MAX_DEVICES] = {};
 
 // Device address of `scratch` on `device`, which must be the current device.  Looked up once per device.
 int scratch_of(int device, unsigned char **out) {
@@ -596,11 +600,17 @@ int check_offsets(const int64_t *offs, int64_t n, const char *what) {
     return STAG_OK;
 }
 
-// Records per sub-batch of the host pipeline (STAG_PIPE_RECORDS overrides it for tests).
-int64_t pipe_records() {
+// Records per sub-batch of the host pipeline (STAG_PIPE_RECORDS overrides it for tests): about 64 MB of text, but
+// no fewer than 65,536 records (smaller launches use the GPU badly: per million reads the walk takes 0.62 ms in
+// launches of 500k, 0.81 ms in launches of 250k and several ms in launches of 65k) and no more than 262,144 (the
+// first upload and the last download of a call overlap with nothing).  Full-width amplicon text (1.5 kB per
+// read) therefore goes in sub-batches of 65,536, trimmed records (0.27 kB) in sub-batches of about 250,000.
+int64_t pipe_records(int64_t n, int64_t text_bytes) {
     const char *e = getenv("STAG_PIPE_RECORDS");
     const long long v = e ? atoll(e) : 0;
-    return v > 0 ? v : 65536;
+    if (v > 0) return v;
+    const int64_t per_record = std::max<int64_t>(text_bytes / std::max<int64_t>(n, 1), 1);
+    return std::min<int64_t>(std::max<int64_t>(((int64_t)64 << 20) / per_record, 65536), 262144);
 }
 
 template <typename T>
@@ -1116,9 +1126,22 @@ int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t tex
     if (n > 0x7fffffff - 1024) return fail(STAG_E_INVALID, "batch of %lld sequences is too large; split it", (long long)n);
     HIP_TRY(hipSetDevice(db->device));
     unsigned char *base = nullptr;
+    hipStream_t st = (hipStream_t)stream;
     {
         std::lock_guard<std::mutex> lock(g_scratch_mu);
         base = db->device < MAX_DEVICES ? g_scratch_ptr[db->device] : nullptr;
+        if (base) {
+            // overlap on one GPU is refused where it can be seen: the previous call went to another stream and
+            // that stream has not drained (hipStreamQuery allocates nothing)
+            if (g_scratch_used[db->device] && g_scratch_stream[db->device] != st &&
+                hipStreamQuery(g_scratch_stream[db->device]) == hipErrorNotReady)
+                return fail(STAG_E_INVALID, "stag_classify_a2m_noalloc_dev: the previous call on this GPU went to another "
+                                            "stream that still has work queued; all such calls share one scratch array "
+                                            "(synchronise that stream first, or use stag_classify_a2m_dev)");
+            (void)hipGetLastError();
+            g_scratch_stream[db->device] = st;
+            g_scratch_used[db->device] = true;
+        }
     }
     if (!base) return fail(STAG_E_HIP, "the scratch array of device %d was not set up (stag_db_create does it)", db->device);
     const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
@@ -1157,7 +1180,6 @@ int stag_classify_a2m_noalloc_dev(stag_db_t *db, const char *d_text, int64_t tex
                     "%lld sequences of this database need %lld bytes of workspace; the static scratch of "
                     "stag_classify_a2m_noalloc_dev holds %lld (split the batch, or use stag_classify_a2m_dev)",
                     (long long)n, (long long)used, (long long)STAG_NOALLOC_SCRATCH_BYTES);
-    hipStream_t st = (hipStream_t)stream;
     int rc;
     if ((rc = encode_dev(nullptr, db->L, d_text, text_bytes, d_offs, n, min_perc_state, wk.bits, wk.enc_n_char, o.n_aligned,
                          wk.enc_status, wk.win, st, nullptr, nullptr, /*full_rows=*/false)))
@@ -1184,7 +1206,7 @@ int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *of
         }
     HIP_TRY(hipSetDevice(db->device));
     // ---- sub-batches: cut at record boundaries, at most PIPE_RECORDS records / PIPE_BYTES bytes each
-    const int64_t PIPE_RECORDS = pipe_records(), PIPE_BYTES = (int64_t)96 << 20;
+    const int64_t PIPE_RECORDS = pipe_records(n, offs[n] - offs[0]), PIPE_BYTES = (int64_t)96 << 20;
     const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
     if (!db->slot[1].down) {   // (the last one taken: a handle whose set-up failed half way takes the rest)
         for (hipStream_t *st : {&db->s_up, &db->s_run, &db->s_down})

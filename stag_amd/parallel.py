@@ -65,7 +65,9 @@ class DevicePool:
     submit(fn, *args) runs fn(database_of_some_device, *args) on the next free device and returns a future;
     at most `depth` batches per device are in flight, so a fast parser cannot run ahead of the GPUs without bound."""
 
-    def __init__(self, make_database, devices, depth=2):
+    def __init__(self, make_database, devices, depth=2, own=True):
+        """own=False: the databases belong to the caller, close() leaves them open."""
+        self._own = own
         import queue
         import threading
         from concurrent.futures import Future
@@ -103,8 +105,9 @@ class DevicePool:
             self._q.put(None)
         for t in self._threads:
             t.join()
-        for db in self.dbs:
-            db.close()
+        if self._own:
+            for db in self.dbs:
+                db.close()
 
 
 def owner_of_batch(batch_index, world):

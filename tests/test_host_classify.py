@@ -612,3 +612,41 @@ def test_long_rows_of_a_batch_equal_the_per_row_formatter():
     want = [db.result_row(res, i, ids[i], True) for i in range(res.n) if res.status[i] == _lib.SEQ_OK]
     assert db.result_rows(res, ids, True) == want and len(want) > 2900
     assert db.result_rows(res, ids, False) == [w[:2] for w in want]
+
+
+def test_paired_batches_stay_full_when_the_batchers_cut_unevenly(monkeypatch, tmp_path):
+    """aligned_batches for a protein database: one batcher cutting at 10 records, the other at 9, used to alternate
+    batches of 9 and 1; both sides are now topped up before a pair is cut, so every batch but the last is full."""
+    from stag_amd import align as sa
+    from stag_amd.tables import pack_text
+
+    def fake_batches(sizes, tag):
+        at = 0
+        for m in sizes:
+            ids = ["r%d" % i for i in range(at, at + m)]
+            text, offs = pack_text(["%s%d" % (tag, i) for i in range(at, at + m)])
+            at += m
+            yield ids, text, offs
+
+    class Proc:
+        stdout = "prot"
+
+    monkeypatch.setattr(sa, "_start_aligner", lambda *a: (Proc(), Proc()))
+    monkeypatch.setattr(sa, "_finish_aligner", lambda *a: None)
+    n = 95
+    monkeypatch.setattr(sa.ingest, "fasta_batches",
+                        lambda stream, **kw: fake_batches([10] * 9 + [5], "P") if stream == "prot" else
+                        fake_batches([9] * 10 + [5], "G"))
+    gene_file = tmp_path / "g.fna"
+    gene_file.write_text(">x\nA\n")
+    got = list(sa.aligned_batches(str(gene_file), "prot.faa", "hmm", False, 1, 1, size=10))
+    sizes = [len(b[0]) for b in got]
+    assert sum(sizes) == n and all(s >= 5 for s in sizes[:-1]) and len(sizes) <= 11
+    at = 0
+    for ids, ptext, poffs, (gtext, goffs), lt in got:
+        assert lt is None
+        for j, sid in enumerate(ids):
+            assert sid == "r%d" % at
+            assert bytes(ptext[poffs[j]:poffs[j + 1]]).decode() == "P%d" % at
+            assert bytes(gtext[goffs[j]:goffs[j + 1]]).decode() == "G%d" % at
+            at += 1

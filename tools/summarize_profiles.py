@@ -12,9 +12,9 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r2"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+SRC = os.path.join(ROOT, "gpurun_out", "final_" + tag)      # written by ONE run of tools/collect_profiles.sh <tag>
 sys.path.insert(0, ROOT)
 from stag_amd._lib import kernel_source_sha1  # noqa: E402
 
@@ -26,8 +26,12 @@ def short(name):
 
 
 def newest(pattern):
-    """gpurun merges every run's files into the same directories: take the latest."""
-    return max(glob.glob(pattern), key=os.path.getmtime)
+    """The one file a run leaves (collect_profiles.sh starts from an empty directory; more than one file means that
+    runs were mixed, and per-launch figures from mixed runs are wrong without looking wrong)."""
+    found = glob.glob(pattern)
+    if len(found) != 1:
+        raise SystemExit("%d files match %s: expected the output of exactly one run" % (len(found), pattern))
+    return found[0]
 
 
 def counter(dirname, cname):
@@ -48,6 +52,17 @@ shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
 
 fetch, nf = counter("pmc_fetch", "FETCH_SIZE")
 write, nw = counter("pmc_write", "WRITE_SIZE")
+# A counter pass is `bench.py --steps 1 --warmup 0`: the timed step and the event-profiled step = 2 passes over the
+# batch, each with ONE encode launch and one walk launch per tree level (7 for the bench database).  Anything else
+# means the totals and the dispatch counts are not of the same run, and dividing them would give a wrong number
+# (round 2: 80 MB per walk launch instead of 272 MB).
+for name, disp in (("FETCH_SIZE", nf), ("WRITE_SIZE", nw)):
+    passes = disp.get("k_encode_a2m", 0)
+    if passes != 2 or disp.get("k_walk_level", 0) != 7 * passes or disp.get("k_rankcut", 0) != passes:
+        raise SystemExit("%s pass: %d encode, %d walk, %d rank-cut dispatches; expected 2, 14, 2"
+                         % (name, passes, disp.get("k_walk_level", 0), disp.get("k_rankcut", 0)))
+if nf != nw:
+    raise SystemExit("the FETCH_SIZE and WRITE_SIZE passes saw different dispatches: %r vs %r" % (nf, nw))
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python3 bench.py --steps 1 --warmup 0 "
                "--no-cpu-baseline --check 0` (two passes over the C2 batch: the timed step and the event-profiled "
                "step). Counter values are KiB as rocprofv3 reports them (x1024 -> bytes); FETCH_SIZE is doubled "
