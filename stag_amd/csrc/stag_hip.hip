@@ -518,9 +518,10 @@ int walk_dev(stag_db *db, const Work &wk, const uint32_t *d_bits, int64_t n, con
     {
         Prof p(db, st, 2, wk.prof);
         HIP_TRY(hipMemsetAsync(wk.count, 0, sizeof(int32_t) * db->n_nodes, st));
-        if (db->max_depth == 0)
+        if (db->max_depth == 0) {
             trace_launch(st, "k_init_status n=%lld", (long long)n);
             hipLaunchKernelGGL(k_init_status, dim3(g256), dim3(256), 0, st, n, d_status_in, o.status);
+        }
     }
     int rc;
     if ((rc = launch_check("k_init_status"))) return rc;
