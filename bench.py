@@ -310,23 +310,31 @@ def main():
             tsv = fh.name
         size = os.path.getsize(tsv)
 
-        def onehot_pass():
-            got = []
-            for ids, tx, bb, be, raw in ingest.onehot_text_batches(tsv, slow_line=parse_onehot_line):
-                got.append(db.classify_onehot_text(tx, bb, be, parse_onehot_line, raw)[0])
+        from stag_amd import parallel as par
+        opool = par.DevicePool(lambda d_: db, [local], own=False)
+
+        def onehot_pass():     # as classify() drives it: one batch inside the library while the next is being read
+            got, pending = [], []
+            for ids, tx, bb, be, raw in ingest.onehot_text_batches(tsv, slow_line=parse_onehot_line, ring_slots=4):
+                pending.append(opool.submit(lambda d_, a=(tx, bb, be, raw): d_.classify_onehot_text(a[0], a[1], a[2], parse_onehot_line, a[3])))
+                while len(pending) >= 2:
+                    got.append(pending.pop(0).result()[0])
+            got += [f.result()[0] for f in pending]
             return got
 
         onehot_pass()
         o0 = time.perf_counter()
         got = onehot_pass()
         odt = time.perf_counter() - o0
+        opool.close()
         os.remove(tsv)
         same = all(np.array_equal(np.concatenate([getattr(g, f) for g in got]), out[f][:m].cpu().numpy())
                    for f in ("path_node", "path_prob", "selected", "n_aligned", "status"))
         onehot_leg = {"value": round(m / odt, 1), "unit": "seqs/s", "lines": m, "file_bytes": int(size),
                       "text_GBs": round(size / odt / 1e9, 2), "equals_device_resident_results": bool(same),
-                      "how": "ingest.onehot_text_batches (file read by a thread into page-locked 32 MB chunks, stag_onehot_lines on one core) + "
-                             "Database.classify_onehot_text (k_parse_onehot + the walk); file in the page cache"}
+                      "how": "ingest.onehot_text_batches (32 MB chunks of whole lines read into page-locked buffers and their lines found "
+                             "by a pool of up to 8 threads) + Database.classify_onehot_text (k_parse_onehot + the walk); "
+                             "file in the page cache"}
 
     if rank != 0:
         if world > 1:

@@ -47,9 +47,28 @@ def alignment_reader(aligned_sequences):
 
 
 def _in_flight(pool):
-    """Batches handed to the devices before the oldest one's result is taken: one per device and one more
-    being prepared for each, or none ahead with a single device (the reference's own order of events)."""
-    return 2 * len(pool.dbs) if len(pool.dbs) > 1 else 1
+    """Batches handed to the devices before the oldest one's result is taken: one per device and one more being
+    prepared for each.  (Also with a single device: its worker thread is inside the library, copying and computing,
+    while this thread turns the previous batch into rows and the readers fetch the next; results are still taken
+    in input order, so files, rows and the first error are those of the reference's one loop.)"""
+    return 2 * len(pool.dbs)
+
+
+def _first_things_first(batches, pending, finish_oldest):
+    """The batches of a reader whose own failure (an identifier mismatch: sys.exit; a malformed line; an aligner that
+    failed) must not overtake what it had already handed out: the batches still in flight are finished first -- one
+    of them may hold an earlier failing sequence, which is where the reference's single loop stops."""
+    it = iter(batches)
+    while True:
+        try:
+            item = next(it)
+        except StopIteration:
+            return
+        except BaseException:
+            while pending:
+                finish_oldest()
+            raise
+        yield item
 
 
 def _classify_prealigned(pool, aligned_sequences, tagged, state):
@@ -72,7 +91,7 @@ def _classify_prealigned(pool, aligned_sequences, tagged, state):
         # the GPU parses the fields (k_parse_onehot): the host only finds the lines and their ids
         batches = ingest.onehot_text_batches(aligned_sequences, batch_rows=READER_BATCH, ring_slots=_in_flight(pool) + 2,
                                              slow_line=parse_onehot_line)
-        for b, (ids, text, bb, be, raw) in enumerate(batches):
+        for b, (ids, text, bb, be, raw) in enumerate(_first_things_first(batches, pending, finish_oldest)):
             if not state["alignment_length"]:
                 state["alignment_length"] = len(parse_onehot_line(raw(0))[1])
             if parallel.owner_of_batch(b, world) != rank:
@@ -86,7 +105,7 @@ def _classify_prealigned(pool, aligned_sequences, tagged, state):
         return
     batches = ingest.onehot_batches(aligned_sequences, L, db.words_per_row, batch_rows=READER_BATCH,
                                     slow_line=parse_onehot_line)
-    for b, (ids, bits, n_fields) in enumerate(batches):
+    for b, (ids, bits, n_fields) in enumerate(_first_things_first(batches, pending, finish_oldest)):
         if not state["alignment_length"]:
             state["alignment_length"] = int(n_fields[0])
         if parallel.owner_of_batch(b, world) != rank:
@@ -199,7 +218,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                         packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
 
             with alignment_out:
-                for b, (ids, text, offs, gene, lead_trail) in enumerate(batches):
+                for b, (ids, text, offs, gene, lead_trail) in enumerate(_first_things_first(batches, pending, finish_oldest)):
                     mine = parallel.owner_of_batch(b, world) == rank
                     if not mine and not want_bits and (state["alignment_length"] or pending):
                         continue

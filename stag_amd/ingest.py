@@ -257,6 +257,15 @@ def onehot_batches(path, n_features, words_per_row, batch_rows=1 << 14, chunk_by
             pending = buf[pos:]
 
 
+# Page-locked buffers that a finished reader hands back, for the next reader OF THE SAME THREAD: locking memory costs
+# about as much as reading it once, which a short file (or a process that classifies file after file) would pay again
+# and again.  (Per thread, because a thread starts its next reader only after it is done with the batches of the
+# last one; another thread's reader could start while those are still being copied to the GPU.)
+_PINNED_SPARE = {}            # (thread, nbytes) -> [(owner, array)]
+_PINNED_SPARE_LOCK = threading.Lock()
+_PINNED_SPARE_MAX = 1 << 30   # bytes kept at most
+
+
 class _PinnedRing:
     """Page-locked byte buffers used in turn, allocated when first used (pageable arrays when the GPU library cannot
     give such memory)."""
@@ -267,6 +276,12 @@ class _PinnedRing:
     def next(self):
         self.turn = (self.turn + 1) % len(self.bufs)
         if self.bufs[self.turn] is None:
+            with _PINNED_SPARE_LOCK:
+                spare = _PINNED_SPARE.get((threading.get_ident(), self.nbytes))
+                got = spare.pop() if spare else None
+            if got is not None:
+                self.bufs[self.turn] = got
+                return got[1]
             try:
                 from . import _lib
                 keep = _lib.PinnedArray(self.nbytes, np.uint8)
@@ -274,6 +289,17 @@ class _PinnedRing:
             except Exception:
                 self.bufs[self.turn] = (None, np.empty(self.nbytes, dtype=np.uint8))
         return self.bufs[self.turn][1]
+
+    def release(self):
+        """The reader is done (and so is everything that read its batches): the page-locked buffers go to the spare
+        list, up to _PINNED_SPARE_MAX bytes in all."""
+        with _PINNED_SPARE_LOCK:
+            held = sum(k[1] * len(v) for k, v in _PINNED_SPARE.items())
+            for item in self.bufs:
+                if item is not None and item[0] is not None and held + self.nbytes <= _PINNED_SPARE_MAX:
+                    _PINNED_SPARE.setdefault((threading.get_ident(), self.nbytes), []).append(item)
+                    held += self.nbytes
+        self.bufs = [None] * len(self.bufs)
 
 
 def _last_line_end(buf, have):
@@ -350,23 +376,155 @@ class _LineChunks:
         self.thread.join(timeout=5.0)
 
 
-def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 25, ring_slots=3, slow_line=None):
+def _line_chunk_starts(mm, chunk_bytes):
+    """Offsets at which chunks of about chunk_bytes begin, each right after a line end ('\n', '\r\n' or a lone
+    '\r': the universal newlines of the reference's text-mode reader); first 0, last len(mm)."""
+    n = len(mm)
+    starts, at = [0], 0
+    while True:
+        at += chunk_bytes
+        if at >= n:
+            break
+        nxt, lo = -1, at
+        while lo < n:
+            hi = min(n, lo + (1 << 16))
+            w = np.asarray(mm[lo:hi])
+            hit = np.flatnonzero((w == 10) | (w == 13))
+            if len(hit):
+                p = lo + int(hit[0])
+                if mm[p] == 13 and p + 1 < n and mm[p + 1] == 10:
+                    p += 1
+                nxt = p + 1
+                break
+            lo = hi
+        if nxt < 0 or nxt >= n:
+            break
+        if nxt > starts[-1]:
+            starts.append(nxt)
+        at = max(at, nxt)
+    starts.append(n)
+    return starts
+
+
+def _read_and_find_lines(fd, begin, end, buf):
+    """Pool thread: file bytes [begin, end) -- whole lines -- into buf (page-locked), then stag_onehot_lines over them.
+    Both release the GIL.  Returns (recs, body_begin, body_end) of the chunk's lines."""
+    L = lib()
+    have, want = 0, end - begin
+    mv = memoryview(buf)
+    while have < want:
+        got = os.preadv(fd, [mv[have:want]], begin + have)
+        if got <= 0:
+            raise OSError("short read: the file changed while it was being read")
+        have += got
+    parts, pos = [], 0
+    while pos < want:
+        room = 4096
+        recs = np.zeros(room, dtype=RECORD)
+        bb = np.zeros(room, dtype=np.int64)
+        be = np.zeros(room, dtype=np.int64)
+        consumed = ctypes.c_int64(0)
+        view = buf[pos:want]
+        n = L.stag_onehot_lines(_ptr(view), len(view), 1, room, _ptr(recs), _ptr(bb), _ptr(be), ctypes.byref(consumed))
+        if n <= 0 or consumed.value <= 0:
+            raise ValueError("stag_onehot_lines: bad arguments")
+        recs = recs[:n]
+        for f in ("id_begin", "raw_begin", "raw_end"):
+            recs[f] += pos
+        parts.append((recs, bb[:n] + pos, be[:n] + pos))
+        pos += consumed.value
+    if not parts:
+        return np.zeros(0, dtype=RECORD), np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64)
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(3))
+
+
+def _reader_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    v = os.environ.get("STAG_THREADS", "")
+    if v.isdigit() and int(v) > 0:
+        n = int(v)
+    return max(1, min(n, 8))       # (eight copies out of the page cache side by side outrun the PCIe link)
+
+
+def onehot_text_batches(path, batch_rows=1 << 14, chunk_bytes=1 << 25, ring_slots=3, slow_line=None, threads=None):
     """Yields (ids, text, body_begin, body_end, raw) for the lines of a -s file WITHOUT parsing their fields:
     text is a uint8 view (of a page-locked buffer, valid until ring_slots - 1 further batches have been produced)
     that holds whole lines, line i's fields are text[body_begin[i]:body_end[i]] (see stag_onehot_lines), and
     raw(i) returns line i as the str the reference would iterate over (for the slow path).  A batch is the whole
     lines of one chunk of the file, at most batch_rows of them.  slow_line(str) -> (id, bool array) names the
     lines the line finder flags (they end in a non-ASCII byte, which may be white space for str.rstrip).
-    The file is read by a thread of its own, one chunk ahead (two buffers more than ring_slots); chunks of 32 MB keep
-    the page-locked memory (and the time it takes to lock it, which a short file would notice) small."""
+    A regular file is cut into chunks of whole lines that a pool of `threads` threads (default: the job's cores, at
+    most 8) reads into page-locked buffers and finds the lines of, a few chunks ahead of the consumer; what comes
+    out is in file order.  Anything else (a FIFO) is read by one thread, one chunk ahead."""
+    try:
+        st = os.stat(path)
+        regular = stat.S_ISREG(st.st_mode)
+    except OSError:
+        regular = False
+    if not regular:
+        yield from _onehot_text_batches_stream(path, batch_rows, chunk_bytes, ring_slots, slow_line)
+        return
+    if st.st_size == 0:
+        return
+    from concurrent.futures import ThreadPoolExecutor
+    threads = threads or _reader_threads()
+    mm = np.memmap(path, dtype=np.uint8, mode="r")
+    starts = _line_chunk_starts(mm, max(int(chunk_bytes), 64))
+    del mm
+    n_chunks = len(starts) - 1
+    threads = max(1, min(threads, n_chunks))
+    cap = max(b - a for a, b in zip(starts[:-1], starts[1:])) + 64       # (room for the GPU copy's padding)
+    cap = (cap + (1 << 20) - 1) >> 20 << 20                              # (sizes that a later reader asks for again)
+    ring = _PinnedRing(threads + ring_slots + 1, cap)
+    n_buf = len(ring.bufs)
+    fd = os.open(path, os.O_RDONLY)
+    pool = ThreadPoolExecutor(threads, thread_name_prefix="stag-onehot-reader")
+    free, held, pending = list(range(n_buf)), [], []
+    try:
+        nxt = 0
+        while nxt < n_chunks or pending:
+            while nxt < n_chunks and len(pending) < threads and free:
+                i = free.pop(0)
+                ring.turn = i - 1
+                buf = ring.next()
+                pending.append((i, buf, starts[nxt + 1] - starts[nxt],
+                                pool.submit(_read_and_find_lines, fd, starts[nxt], starts[nxt + 1], buf)))
+                nxt += 1
+            i, buf, have, fut = pending.pop(0)
+            recs_all, bb_all, be_all = fut.result()
+            held.append(i)
+            while len(held) > ring_slots:
+                free.append(held.pop(0))
+            for r0 in range(0, len(recs_all), batch_rows):
+                recs = recs_all[r0:r0 + batch_rows]
+                lo, hi = int(recs["raw_begin"][0]), int(recs["raw_end"][-1])
+                text = buf[lo:hi]
+                mv = memoryview(text)
+                begins = (recs["id_begin"] - lo).tolist()
+                ends = (recs["id_begin"] + recs["id_len"] - lo).tolist()
+                ids = [str(mv[b:e], "utf-8") for b, e in zip(begins, ends)]
+
+                def raw(i, mv=mv, rb=recs["raw_begin"] - lo, re_=recs["raw_end"] - lo):
+                    return str(mv[int(rb[i]):int(re_[i])], "utf-8")
+
+                for i in np.flatnonzero(recs["flag"] == FALLBACK):
+                    ids[i] = slow_line(raw(int(i)))[0]
+                yield ids, text, bb_all[r0:r0 + batch_rows] - lo, be_all[r0:r0 + batch_rows] - lo, raw
+    finally:
+        for _, _, _, fut in pending:
+            fut.cancel()
+        pool.shutdown(wait=True)
+        os.close(fd)
+        ring.release()
+
+
+def _onehot_text_batches_stream(path, batch_rows, chunk_bytes, ring_slots, slow_line):
+    """onehot_text_batches for something that cannot be read at an offset: one reader thread, one chunk ahead."""
     L = lib()
     cap = max(int(chunk_bytes), 64)
-    try:                                  # a small regular file needs no full-size buffers
-        st = os.stat(path)
-        if stat.S_ISREG(st.st_mode):
-            cap = min(cap, max(st.st_size + 64, 1 << 16))
-    except OSError:
-        pass
     chunks = _LineChunks(path, _PinnedRing(ring_slots + 2, cap), cap)
     try:
         for buf, have in chunks:

@@ -24,6 +24,7 @@ import numpy as np
 from . import _lib, ingest
 
 c_p = ctypes.c_void_p
+CHUNK_BYTES = 48 << 20      # file bytes per chunk = per batch (about 31,000 amplicon reads of a 1,500-column alignment)
 
 
 def default_threads():
@@ -133,7 +134,7 @@ def _scan_chunk(index, view, at_start, text_buf, trim):
                  id_buf=view, id_begin=recs["id_begin"].copy(), id_len=recs["id_len"].copy())
 
 
-def a2m_file_batches(path, threads=None, chunk_bytes=48 << 20, trim=True, keep=2, world=1, rank=0):
+def a2m_file_batches(path, threads=None, chunk_bytes=None, trim=True, keep=2, world=1, rank=0):
     """Yields Batch objects for the chunks of an A2M / FASTA file, in file order, scanned by `threads` threads.
     A batch's text sits in one of a set of page-locked buffers and stays valid until `keep` further batches have
     been yielded.  Under a launcher with several ranks (world > 1) a rank scans only its own chunks (chunk b
@@ -144,7 +145,7 @@ def a2m_file_batches(path, threads=None, chunk_bytes=48 << 20, trim=True, keep=2
     if size == 0:
         return
     buf = np.memmap(path, dtype=np.uint8, mode="r")
-    starts = chunk_starts(buf, max(int(chunk_bytes), 1 << 16))
+    starts = chunk_starts(buf, max(int(chunk_bytes or CHUNK_BYTES), 1 << 16))
     n_chunks = len(starts) - 1
     cap = max(b - a for a, b in zip(starts[:-1], starts[1:])) + 64
     n_buf = threads + keep + 1
@@ -229,7 +230,7 @@ def format_short_rows(db, res, batch):
     return out[:m]
 
 
-def classify_a2m_file(pool, path, output=None, threads=None, min_perc_state=0, chunk_bytes=48 << 20, header=True):
+def classify_a2m_file(pool, path, output=None, threads=None, min_perc_state=0, chunk_bytes=None, header=True):
     """A2M file -> the reference's short output (header line `sequence<tab>taxonomy`, then one line per sequence
     that passed the filter, classify.py:172-190) in `output` (stdout when None; written to a temp file and moved
     into place as the reference does).  `pool` is a parallel.DevicePool (or anything with .first / .submit / .dbs):

@@ -59,7 +59,17 @@ static void run_fasta(const char *text, int64_t len) {
         int64_t *offs = (int64_t *)malloc(sizeof(int64_t) * (size_t)(max_rec + 1));
         stag_record_t *recs = (stag_record_t *)malloc(sizeof(stag_record_t) * (size_t)max_rec);
         int64_t consumed = -1, text_used = -1;
-        const int64_t n = stag_fasta_scan(buf, avail, final, at_start, max_rec, out, cap, used_in, offs, recs, &consumed, &text_used);
+        /* every other call asks for the trimmed form: two counts per record, exactly sized */
+        const int trim = (int)below(2);
+        int32_t *lt = trim ? (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)max_rec) : NULL;
+        const int64_t n = trim ? stag_fasta_scan_trim(buf, avail, final, at_start, max_rec, out, cap, used_in, offs, recs, &consumed, &text_used, lt)
+                               : stag_fasta_scan(buf, avail, final, at_start, max_rec, out, cap, used_in, offs, recs, &consumed, &text_used);
+        if (n >= 0 && trim)
+            for (int64_t i = 0; i < n; ++i) {
+                if (lt[2 * i] < 0 || lt[2 * i + 1] < 0) abort();
+                if (offs[i + 1] > offs[i] && (out[offs[i]] == '-' || out[offs[i + 1] - 1] == '-') && recs[i].flag == STAG_INGEST_OK) abort();
+            }
+        free(lt);
         if (n >= 0) {
             if (n > max_rec || consumed < 0 || consumed > avail || text_used < used_in || text_used > cap) abort();
             for (int64_t i = 0; i < n; ++i)
@@ -123,6 +133,28 @@ static void run_format(void) {
     free(bits); free(id_off); free(ids); free(out);
 }
 
+static void run_rows(void) {
+    const int64_t n = below(6), n_str = 1 + below(3);
+    char ids[64];
+    int64_t id_begin[8], id_len[8], str_off[8];
+    int32_t key[8];
+    char blob[64];
+    for (int i = 0; i < 64; ++i) { ids[i] = (char)('a' + i % 26); blob[i] = (char)('A' + i % 26); }
+    str_off[0] = 0;
+    for (int64_t j = 0; j < n_str; ++j) str_off[j + 1] = str_off[j] + below(9);
+    int64_t want = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        id_len[i] = below(8);
+        id_begin[i] = below(64 - id_len[i]);
+        key[i] = (int32_t)below(n_str + 1) - 1;
+        if (key[i] >= 0) want += id_len[i] + 2 + (str_off[key[i] + 1] - str_off[key[i]]);
+    }
+    char *out = (char *)malloc(want > 0 ? (size_t)want : 1);    /* exactly sized */
+    if (stag_rows_format_short(ids, id_begin, id_len, key, n, blob, str_off, out, want) != want) abort();
+    if (want > 0 && stag_rows_format_short(ids, id_begin, id_len, key, n, blob, str_off, out, want - 1) != -want - 1) abort();
+    free(out);
+}
+
 int main(int argc, char **argv) {
     const int iters = argc > 1 ? atoi(argv[1]) : 2000;
     for (int it = 0; it < iters; ++it) {
@@ -141,6 +173,7 @@ int main(int argc, char **argv) {
         run_onehot(t, len, nf, 1);
         free(t);
         run_format();
+        run_rows();
     }
     printf("ok %d\n", iters);
     return 0;

@@ -144,3 +144,67 @@ def test_classify_a2m_gives_classifys_output_file(engine, tmp_path, monkeypatch,
     cli_out = tmp_path / "cli.tsv"
     main(["classify", "-d", db_path, "--a2m", path, "-o", str(cli_out), "-v", "1", "-m", "25"] + (["-l"] if long_out else []))
     assert cli_out.read_bytes() == ref_out.read_bytes()
+
+
+A2M_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests"))
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+import stag_amd.classify as sc
+from stag_amd import stream
+from fake_engine import OracleDatabase
+sc.Database = OracleDatabase
+stream.CHUNK_BYTES = 1 << 16       # several chunks, so that both ranks own some
+seen = []
+real = stream._scan_chunk
+def spy(index, *a, **k):
+    seen.append(index)
+    return real(index, *a, **k)
+stream._scan_chunk = spy
+ret = sc.classify_a2m({db!r}, {a2m!r}, output={out!r} + ".rank" + sys.argv[1], verbose=1, min_perc_state=25, threads=2, cache=False)
+json.dump([list(ret), sorted(seen)], open({out!r} + ".ret" + sys.argv[1], "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_classify_a2m_world2_gloo_ranks_scan_their_own_chunks(tmp_path):
+    """Two ranks (gloo, CPU engine): each scans only the chunks it owns (it seeks; the other rank's chunks are never
+    parsed), rows come back to rank 0 in file order, and rank 0's file is the single-process file."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    import stagdb_writer
+    if not stagdb_writer.available():
+        pytest.skip("tests/csrc/libstagdb_writer.so not built")
+    from stag_amd import classify as sc
+    from fake_engine import OracleDatabase
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(8)
+    ncol = 120
+    db_path = _db_file(tmp_path, rng, ncol)
+    path, ids, recs = make_file(tmp_path, rng, ncol, 2500)
+    single = tmp_path / "single.tsv"
+    real_db, real_chunk = sc.Database, stream.CHUNK_BYTES
+    sc.Database, stream.CHUNK_BYTES = OracleDatabase, 1 << 16
+    try:
+        n1, lines1 = sc.classify_a2m(db_path, path, output=str(single), verbose=1, min_perc_state=25, threads=2, cache=False)
+    finally:
+        sc.Database, stream.CHUNK_BYTES = real_db, real_chunk
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "dist")
+    code = A2M_WORKER.format(root=root, port=port, db=db_path, a2m=path, out=out)
+    procs = [subprocess.Popen([sys.executable, "-c", code, str(r)], stderr=subprocess.PIPE) for r in range(2)]
+    for p in procs:
+        _, err = p.communicate(timeout=180)
+        assert p.returncode == 0, err.decode()[-2000:]
+    assert open(out + ".rank0").read() == single.read_text()
+    assert not os.path.exists(out + ".rank1")
+    (ret0, seen0), (ret1, seen1) = json.load(open(out + ".ret0")), json.load(open(out + ".ret1"))
+    assert ret0 == [n1, lines1] and ret1[1] == 0
+    assert seen0 and seen1 and all(b % 2 == 0 for b in seen0) and all(b % 2 == 1 for b in seen1)
+    assert sorted(seen0 + seen1) == list(range(len(seen0) + len(seen1)))
