@@ -8,7 +8,7 @@ O=$R/gpurun_out/levels_$WL
 rm -rf $O/trace
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --check 0 --host-steps 0 --onehot-lines 0 > $O/trace.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --check 0 --host-steps 0 --onehot-lines 0 --a2m-reads 0 > $O/trace.log 2>&1
 python3 - "$O" <<'PY'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/trace/**/*kernel_trace.csv", recursive=True)[0]
