@@ -51,6 +51,8 @@ WORKLOADS = {
     "c2": "C2: 16S amplicon stagDB, 1M synthetic 250-bp V4 reads pre-aligned, per GPU",
     "c3": "C3 shape: marker-gene stagDB (ncol 1050 = 350 aa x 3), synthetic full-length genes as codon alignments, per GPU",
     "c5": "C5 shape: ~50k-node taxonomy at the 16S width, synthetic 250-bp reads pre-aligned, per GPU",
+    "c3p": "C3 through the protein entry point: marker-gene stagDB (350 aa), synthetic (protein alignment, gene) pairs, "
+           "back-translated on the GPU (align.py:63-94), per GPU",
 }
 
 
@@ -101,10 +103,31 @@ def main():
     if args.workload == "c2":
         wl = bw.config_16s(seed=2, scale=args.db_scale)
     else:
-        wl = bw.config_c3() if args.workload == "c3" else bw.config_c5()
+        wl = bw.config_c5() if args.workload == "c5" else bw.config_c3()
     t = wl.tables
     n = args.reads
-    text, offs, _ = bw.make_reads(wl, seed=1000 + rank, n=n, **({"window": wl.ncol} if args.workload == "c3" else {}))
+    protein = args.workload == "c3p"
+    text, offs, _ = bw.make_reads(wl, seed=1000 + rank, n=n, **({"window": wl.ncol, "max_ins": 0 if protein else 3}
+                                                                if args.workload in ("c3", "c3p") else {}))
+    if protein:
+        # (protein alignment, gene) pairs whose back-translation is `text`: 4 % of the codons are alignment gaps
+        # ('-' in the protein, nothing in the gene), every second gene ends in a stop codon (align.py:66-69)
+        rng = np.random.default_rng(77 + rank)
+        naa = wl.ncol // 3
+        nt = text[:offs[-1]].reshape(n, naa, 3)
+        gap = rng.random((n, naa)) < 0.04
+        nt[gap] = ord("-")
+        prot = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)[rng.integers(0, 20, size=(n, naa))]
+        prot[gap] = ord("-")
+        stop = np.arange(n) % 2 == 1
+        ext = np.concatenate([nt.reshape(n, 3 * naa), np.tile(np.frombuffer(b"TAA", dtype=np.uint8), (n, 1))], axis=1)
+        mask = np.concatenate([np.repeat(~gap, 3, axis=1), np.repeat(stop[:, None], 3, axis=1)], axis=1)
+        gene_text = ext[mask]
+        gene_offs = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(mask.sum(axis=1), out=gene_offs[1:])
+        prot_text = prot.reshape(-1)
+        prot_offs = np.arange(n + 1, dtype=np.int64) * naa
+        del ext, mask
     text = np.concatenate([text, np.zeros(-len(text) % 16, dtype=np.uint8)])    # the _dev ABI wants a 16-byte multiple
     db = Database(t, device=local)
     D, K, W = db.max_depth, db.n_keys, db.words_per_row
@@ -128,9 +151,20 @@ def main():
     stream = torch.cuda.current_stream(dev)
     lib = _lib.lib()
 
-    def step():
-        _lib.check(lib.stag_classify_a2m_dev(db.handle, d_text.data_ptr(), len(text), d_offs.data_ptr(), n, 0.0,
-                                             ctypes.byref(res), stream.cuda_stream))
+    if protein:
+        d_prot = torch.from_numpy(np.concatenate([prot_text, np.zeros(16, np.uint8)])).to(dev)
+        d_prot_offs = torch.from_numpy(prot_offs).to(dev)
+        d_gene = torch.from_numpy(np.concatenate([gene_text, np.zeros(16, np.uint8)])).to(dev)
+        d_gene_offs = torch.from_numpy(gene_offs).to(dev)
+
+        def step():
+            _lib.check(lib.stag_classify_protein_a2m_dev(db.handle, d_prot.data_ptr(), int(prot_offs[-1]), d_prot_offs.data_ptr(),
+                                                         d_gene.data_ptr(), d_gene_offs.data_ptr(), n, 0.0, ctypes.byref(res),
+                                                         stream.cuda_stream))
+    else:
+        def step():
+            _lib.check(lib.stag_classify_a2m_dev(db.handle, d_text.data_ptr(), len(text), d_offs.data_ptr(), n, 0.0,
+                                                 ctypes.byref(res), stream.cuda_stream))
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -343,7 +377,7 @@ def main():
 
     n_ok = int((out["status"] == 0).sum().item())
     # ---- algorithmic bytes: B_seq = A + ncol + R
-    A = float(offs[-1]) / n
+    A = (float(prot_offs[-1]) + float(gene_offs[-1])) / n if protein else float(offs[-1]) / n      # input bytes per read
     ncol = wl.ncol
     R = D * 12 + K * 8 + 12
     b_seq = A + ncol + R

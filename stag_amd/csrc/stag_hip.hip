@@ -1416,17 +1416,32 @@ static int classify_protein_dev(stag_db_t *db, const char *d_prot, int64_t prot_
         return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
     HIP_TRY(hipSetDevice(db->device));
-    const int64_t bt_bytes = (3 * prot_bytes + 31) / 16 * 16;
+    // (4 bytes of room per alignment character: every record's codon alignment then starts on a dword, which is what
+    // lets k_backtranslate_fast move everything in dwords)
+    const int64_t bt_bytes = (4 * prot_bytes + 31) / 16 * 16;
     int rc;
     if ((rc = stag_db_reserve(db, n, bt_bytes)) || (rc = db->bt_text.reserve(bt_bytes)) || (rc = db->bt_begin.reserve(n)) ||
         (rc = db->bt_end.reserve(n)) || (rc = db->bt_status.reserve(n)))
         return rc;
     hipStream_t st = (hipStream_t)stream;
     {
+        if ((n + 3) / 4 > 0x7fffffff) return fail(STAG_E_INVALID, "batch too large");
+        CHK_TEMP_CLEAR();
+        CHK_TEMP(d_prot, prot_bytes); CHK_TEMP(d_prot_offs, (n + 1) * 8); CHK_TEMP(d_gene_offs, (n + 1) * 8);
+#ifdef STAG_CHECKED
+        {   // the gene text has no size argument: it ends where the last gene does
+            int64_t gene_bytes = 0;
+            HIP_TRY(hipMemcpy(&gene_bytes, d_gene_offs + n, sizeof gene_bytes, hipMemcpyDeviceToHost));
+            CHK_TEMP(d_gene, gene_bytes);
+        }
+#endif
+        CHK_UPLOAD();
         Prof p(db, st, 4);
-        if ((rc = stag_backtranslate_dev(d_prot, prot_bytes, d_prot_offs, d_gene, d_gene_offs, n, 1, (char *)db->bt_text.p,
-                                         bt_bytes, db->bt_begin.p, db->bt_end.p, db->bt_status.p, stream)))
-            return rc;
+        trace_launch(st, "k_backtranslate_fast n=%lld prot_bytes=%lld", (long long)n, (long long)prot_bytes);
+        hipLaunchKernelGGL(k_backtranslate_fast, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const uint8_t *)d_prot,
+                           prot_bytes, d_prot_offs, (const uint8_t *)d_gene, d_gene_offs, n, db->bt_text.p, db->bt_begin.p,
+                           db->bt_end.p, db->bt_status.p);
+        if ((rc = launch_check("k_backtranslate_fast"))) return rc;
     }
     const Out o = resolve(db, d_out);
     if ((rc = encode_dev(db, db->L, (const char *)db->bt_text.p, bt_bytes, db->bt_begin.p, n, min_perc_state, db->bits.p,

@@ -565,6 +565,156 @@ __global__ __launch_bounds__(256) void k_backtranslate(const uint8_t *__restrict
     if (lane == 0) { WR(out_begin, rec, o0); WR(out_end, rec, o0 + emitted); WR(status, rec, 0); }
 }
 
+// The same back-translation for the fused protein path (stag_classify_protein_a2m*), which owns its output buffer and
+// so can lay it out for speed: record i's output starts at 4 * prot_offs[i] -- always dword-aligned.  k_backtranslate
+// spends its time issuing instructions (two wave scans and a round of shuffles per 64 characters, one byte load /
+// store per lane and character: about 900 wave instructions for a 350-residue pair, 1.83 ms per million pairs).
+// Here a lane takes BT_CPL = 8 consecutive characters, so a step covers 512 of them -- a 350-residue alignment is ONE
+// step, with one pair of scans -- and all global traffic is in dwords: the gene bytes the step consumes (at most 1,536)
+// are staged into LDS by dword loads, every lane writes what its characters emit into an LDS tile, and the tile's whole
+// dwords leave by dword stores; the 0..3 bytes left over stay at the head of the tile for the next step (the last ones of
+// a record leave as bytes).  The length check of align.py:66-74 is made in the same pass when the alignment is one step
+// long.  The same characters out, the same status 8.
+constexpr int BT_CPL = 8;                          // characters per lane and step
+constexpr int BT_STEP = 64 * BT_CPL;               // characters per step
+constexpr int BT_TILE_WORDS = (3 * BT_STEP + 3) / 4 + 4;   // dwords of a step's gene bytes / output, plus alignment slack
+constexpr int BT_GENE_DW = (BT_TILE_WORDS + 63) / 64;      // staged gene dwords per lane
+
+__global__ __launch_bounds__(256, 8) void k_backtranslate_fast(const uint8_t *__restrict__ prot, int64_t prot_bytes,
+                                                               const int64_t *__restrict__ prot_offs,
+                                                               const uint8_t *__restrict__ gene,
+                                                               const int64_t *__restrict__ gene_offs, int64_t n,
+                                                               uint8_t *__restrict__ out,
+                                                               int64_t *__restrict__ out_begin, int64_t *__restrict__ out_end,
+                                                               int32_t *__restrict__ status) {
+    __shared__ uint32_t s_bt[4][2][BT_TILE_WORDS];   // per wave: gene bytes of the step | output tile
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t rec = (int64_t)blockIdx.x * 4 + wave;
+    if (rec >= n) return;
+    uint32_t *const s_gene = s_bt[wave][0], *const s_out = s_bt[wave][1];
+    uint8_t *const s_gene8 = reinterpret_cast<uint8_t *>(s_gene), *const s_out8 = reinterpret_cast<uint8_t *>(s_out);
+    // everything below is addressed as (wave-uniform base) + (32-bit offset): a record is shorter than 2 GB
+    const int64_t p0 = RDC(prot_offs, rec), p1 = RDC(prot_offs, rec + 1);
+    const int64_t g0 = RDC(gene_offs, rec), glen64 = RDC(gene_offs, rec + 1) - g0;
+    const int plen = (int)(p1 - p0), glen = (int)glen64;
+    const int tail_ok = (int)min((int64_t)plen, prot_bytes - p0);      // characters that may be read in whole dwords
+    const uint8_t *const rp = prot + p0, *const rg = gene + g0;
+    const int64_t o0 = 4 * p0;                    // dword-aligned whenever `out` is
+    uint8_t *const ro = out + o0;
+    uint32_t *const ro32 = reinterpret_cast<uint32_t *>(ro);
+    auto reject = [&]() {                         // align.py:66-74: the reference returns None here
+        if (lane == 0) { WR(out_begin, rec, o0); WR(out_end, rec, o0); WR(status, rec, 8); }
+    };
+    // dword d of this lane's characters from record position q on ('.', a character that does nothing, past the end)
+    auto load_dword = [&](int q) {
+        uint32_t w = 0x2e2e2e2eu;
+        if (q + 4 <= tail_ok) {
+            w = RD(reinterpret_cast<const uint32_t *>(rp + q), 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (q + j < plen) w = (w & ~(0xffu << (8 * j))) | ((uint32_t)RD(rp, q + j) << (8 * j));
+        }
+        return w;
+    };
+    // per dword: byte masks (0x80 per byte) of '-', 'A'..'Z', 'a'..'z'
+    auto classes = [](uint32_t w, uint32_t &dash, uint32_t &upper, uint32_t &lower) {
+        const uint32_t t = w & 0x7f7f7f7fu, hi = w & 0x80808080u;
+        const uint32_t y = w ^ 0x2d2d2d2du;
+        dash = ~(((y & 0x7f7f7f7fu) + 0x7f7f7f7fu) | y) & 0x80808080u;
+        upper = ((t + 0x3f3f3f3fu) & ~(t + 0x25252525u)) & ~hi & 0x80808080u;     // 0x41 <= t <= 0x5a
+        lower = ((t + 0x1f1f1f1fu) & ~(t + 0x05050505u)) & ~hi & 0x80808080u;     // 0x61 <= t <= 0x7a
+    };
+    const bool one_step = plen <= BT_STEP;
+    if (!one_step) {        // a long alignment: the length check needs every character before the first is written
+        int nondash = 0;
+        for (int q = lane * BT_CPL; q < plen; q += BT_STEP)
+#pragma unroll
+            for (int d = 0; d < BT_CPL / 4; ++d) {
+                uint32_t dash, upper, lower;
+                classes(load_dword(q + 4 * d), dash, upper, lower);
+                nondash += min(4, max(0, plen - (q + 4 * d))) - __popc(dash);
+            }
+        const int64_t residues = wave_sum(nondash);
+        if (glen64 != 3 * residues && glen64 - 3 != 3 * residues) { reject(); return; }
+    }
+    int consumed = 0, emitted = 0;                // residues that took a codon / characters written, before this step
+    for (int base = 0; base < plen; base += BT_STEP) {
+        // ---- the gene bytes this step can consume (at most 3 per character) are fetched first, in dwords that are
+        // aligned in memory, so that they travel while the characters are read and counted
+        const int G0 = 3 * consumed, gspan = min(glen - G0, 3 * BT_STEP);
+        const int gshift = (int)(reinterpret_cast<uintptr_t>(rg + G0) & 3);
+        const int nd = gspan > 0 ? (gshift + gspan + 3) >> 2 : 0;                  // <= BT_TILE_WORDS - 3
+        const uint8_t *const gbase = rg + (G0 - gshift);                           // wave-uniform, dword-aligned
+        uint32_t gv[BT_GENE_DW];
+#pragma unroll
+        for (int i = 0; i < BT_GENE_DW; ++i) {
+            const int d = lane + 64 * i;
+            gv[i] = 0;
+            if (d < nd) {
+                if (4 * d + 4 - gshift <= glen - G0) {
+                    gv[i] = RD(reinterpret_cast<const uint32_t *>(gbase), d);
+                } else {                                            // the record's last dword: only its own bytes
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int off = 4 * d + j - gshift;         // relative to G0
+                        if (off >= -G0 && off < glen - G0) gv[i] |= (uint32_t)RD(gbase, 4 * d + j) << (8 * j);
+                    }
+                }
+            }
+        }
+        const int q = base + lane * BT_CPL;
+        uint32_t w[BT_CPL / 4], dash[BT_CPL / 4], upper[BT_CPL / 4], lower[BT_CPL / 4];
+        int takes = 0, e = 0, nondash = 0;
+#pragma unroll
+        for (int d = 0; d < BT_CPL / 4; ++d) {
+            w[d] = load_dword(q + 4 * d);
+            classes(w[d], dash[d], upper[d], lower[d]);
+            takes += __popc(upper[d] | lower[d]);
+            e += 3 * __popc(dash[d] | upper[d]);
+            nondash += min(4, max(0, plen - (q + 4 * d))) - __popc(dash[d]);       // what align.py:65 counts
+        }
+        if (one_step) {
+            const int64_t residues = wave_sum(nondash);
+            if (glen64 != 3 * residues && glen64 - 3 != 3 * residues) { reject(); return; }
+        }
+        // (after the length check a codon is never cut short by the gene's end: 3 * letters <= 3 * residues <= glen)
+        const int t_incl = wave_incl_scan(takes, lane), e_incl = wave_incl_scan(e, lane);
+        const int t_total = __shfl(t_incl, 63), e_total = __shfl(e_incl, 63);
+        // ---- the staged gene bytes -> LDS
+#pragma unroll
+        for (int i = 0; i < BT_GENE_DW; ++i)
+            if (lane + 64 * i < nd) s_gene[lane + 64 * i] = gv[i];
+        // ---- this lane's characters -> the output tile, behind the bytes the last step left over
+        const int oshift = emitted & 3;
+        int at = oshift + e_incl - e;                                       // in the tile
+        int from = 3 * (t_incl - takes) + gshift;                           // in the staged gene bytes
+#pragma unroll
+        for (int d = 0; d < BT_CPL / 4; ++d)
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t bit = 0x80u << (8 * j);
+                const bool is_dash = dash[d] & bit, is_upper = upper[d] & bit, is_lower = lower[d] & bit;
+                if (is_dash || is_upper) {
+                    for (int b = 0; b < 3; ++b) s_out8[at + b] = is_dash ? (uint8_t)'-' : s_gene8[from + b];
+                    at += 3;
+                }
+                from += (is_upper || is_lower) ? 3 : 0;
+            }
+        // ---- whole dwords of the tile -> memory; what is left over moves to the tile's head
+        const int total = oshift + e_total, nd_out = total >> 2;
+        for (int d = lane; d < nd_out; d += 64) WR(ro32, ((emitted - oshift) >> 2) + d, s_out[d]);
+        const uint32_t left = s_out[nd_out];
+        if (lane == 0) s_out[0] = left;
+        consumed += t_total;
+        emitted += e_total;
+    }
+    const int rest = emitted & 3;
+    if (lane < rest) WR(ro, (emitted - rest) + lane, s_out8[lane]);
+    if (lane == 0) { WR(out_begin, rec, o0); WR(out_end, rec, o0 + emitted); WR(status, rec, 0); }
+}
+
 // ------------------------------------------------------------------------------------------
 // -s lines: stag/classify.py:16-20 (alignment_reader) for lines in the form stag itself writes (-S,
 // classify.py:160-162): after the id, fields that are the single characters '0' / '1', separated by single tabs.
