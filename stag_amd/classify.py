@@ -203,7 +203,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                     # lines of the sequences before it (classify.py:158-162)
                     before = np.flatnonzero(res.status[:failed[0]] == _lib.SEQ_OK)
                     if want_bits and len(before):
-                        alignment_out.write(ingest.format_onehot([ids[i] for i in before], res.bits[before], db.n_features))
+                        alignment_out.write(ingest.format_onehot([ids[i] for i in before], res.bits[before], db.n_features, as_view=True))
                     raise_for_status(res.status, ids)
                 passed = np.flatnonzero(res.status == _lib.SEQ_OK)
                 n_pass += len(passed)
@@ -213,7 +213,7 @@ def classify(database, fasta_input=None, protein_fasta_input=None, verbose=3, th
                 if mine:
                     tagged.append((b, db.result_rows(res, ids, long_out=state["long_rows"])))
                 if want_bits and len(passed):      # classify.py:160-162
-                    alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed], db.n_features))
+                    alignment_out.write(ingest.format_onehot([ids[i] for i in passed], res.bits[passed], db.n_features, as_view=True))
                     if packed_rows_out is not None:
                         packed_rows_out.append(([ids[i] for i in passed], res.bits[passed]))
 

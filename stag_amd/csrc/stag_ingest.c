@@ -262,6 +262,9 @@ int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, 
     int64_t need = 0;
     for (int64_t i = 0; i < n; ++i) need += (id_off[i + 1] - id_off[i]) + 1 + (n_features ? 2 * (int64_t)n_features - 1 : 0) + 1;
     if (need > out_cap) return -need;
+    char lut[256][16];
+    for (int v = 0; v < 256; ++v)
+        for (int k = 0; k < 8; ++k) { lut[v][2 * k] = (char)('0' + ((v >> k) & 1)); lut[v][2 * k + 1] = '\t'; }
     char *o = out;
     for (int64_t i = 0; i < n; ++i) {
         const int64_t il = id_off[i + 1] - id_off[i];
@@ -269,10 +272,18 @@ int64_t stag_onehot_format(const uint32_t *bits, int64_t n, int32_t n_features, 
         o += il;
         *o++ = '\t';   /* print(id, "", sep="\t") also writes the separator when there are no features */
         const uint32_t *row = bits + (size_t)i * words_per_row;
-        for (int32_t f = 0; f < n_features; ++f) {
-            *o++ = (char)('0' + ((row[f >> 5] >> (f & 31)) & 1u));
-            if (f + 1 < n_features) *o++ = '\t';
+        /* eight features at a time: byte b of the row -> the 16 characters "x\tx\t...x\t" from a table (the last
+         * feature's tab is taken back below); the text is 2 bytes per feature, so this loop is the cost of -S */
+        int32_t f = 0;
+        for (; f + 8 <= n_features; f += 8) {
+            memcpy(o, lut[(row[f >> 5] >> (f & 31)) & 0xffu], 16);
+            o += 16;
         }
+        for (; f < n_features; ++f) {
+            *o++ = (char)('0' + ((row[f >> 5] >> (f & 31)) & 1u));
+            *o++ = '\t';
+        }
+        if (n_features > 0) --o;   /* no tab behind the last feature */
         *o++ = '\n';
     }
     return (int64_t)(o - out);

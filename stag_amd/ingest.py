@@ -558,8 +558,10 @@ def _onehot_text_batches_stream(path, batch_rows, chunk_bytes, ring_slots, slow_
         chunks.close()
 
 
-def format_onehot(ids, bits, n_features):
-    """The -S lines (classify.py:160-162) for packed rows, as bytes."""
+def format_onehot(ids, bits, n_features, as_view=False):
+    """The -S lines (classify.py:160-162) for packed rows, as bytes (as_view: as a memoryview of the buffer they were
+    written into, for a caller that only hands them to write(): the text is 2 bytes per feature, and one more copy
+    of it costs more than producing it)."""
     bits = np.ascontiguousarray(bits, dtype=np.uint32)
     n = len(ids)
     enc = [s.encode("utf-8") for s in ids]
@@ -572,4 +574,4 @@ def format_onehot(ids, bits, n_features):
     m = lib().stag_onehot_format(_ptr(bits), n, n_features, w, _ptr(blob), _ptr(id_off), _ptr(out), cap)
     if m < 0:
         raise RuntimeError("stag_onehot_format: buffer too small (%d)" % -m)
-    return out[:m].tobytes()
+    return memoryview(out)[:m] if as_view else out[:m].tobytes()

@@ -50,19 +50,22 @@ def main():
         t_db = time.perf_counter() - t0
         present = rng.random((n_genomes, n_genes)) < 0.9
         present[:, 0] |= ~present.any(axis=1)
-        mgs, n_seq = {}, 0
-        for i, g in enumerate(genes):
-            rows = np.flatnonzero(present[:, i])
-            n_seq += len(rows)
-            ids = ["GENOME%06d_%d##%s" % (j, i + 1, g) for j in rows]
-            with open(os.path.join(tmp, g + "_genes.fna"), "w") as fh:
-                fh.write("".join(">%s\nACGT\n" % s for s in ids))
-            with open(os.path.join(tmp, g + ".fna.a2m"), "wb") as fh:
-                for c0 in range(0, len(rows), 2000):
-                    part = rows[c0:c0 + 2000]
-                    text, offs, _ = bw.make_reads(cwl, seed=1000 * i + c0, n=len(part), window=n_genes * gcol, max_ins=0)
-                    block = text[:offs[-1]].reshape(len(part), n_genes * gcol)[:, i * gcol:(i + 1) * gcol]
-                    fh.write(b"".join(b">%s\n%s\n" % (s.encode(), block[r].tobytes()) for r, s in enumerate(ids[c0:c0 + 2000])))
+        mgs, n_seq = {}, int(present.sum())
+        fna = {g: open(os.path.join(tmp, g + "_genes.fna"), "w") for g in genes}
+        a2m = {g: open(os.path.join(tmp, g + ".fna.a2m"), "wb") for g in genes}
+        for c0 in range(0, n_genomes, 2000):          # one pass over the genomes: a genome's genes are cut from one read
+            m = min(2000, n_genomes - c0)
+            text, offs, _ = bw.make_reads(cwl, seed=1000 + c0, n=m, window=n_genes * gcol, max_ins=0)
+            whole = text[:offs[-1]].reshape(m, n_genes * gcol)
+            for i, g in enumerate(genes):
+                rows = np.flatnonzero(present[c0:c0 + m, i])
+                ids = ["GENOME%06d_%d##%s" % (c0 + j, i + 1, g) for j in rows]
+                fna[g].write("".join(">%s\nACGT\n" % s for s in ids))
+                block = whole[rows, i * gcol:(i + 1) * gcol]
+                a2m[g].write(b"".join(b">%s\n%s\n" % (s.encode(), block[r].tobytes()) for r, s in enumerate(ids)))
+        for g in genes:
+            fna[g].close()
+            a2m[g].close()
             mgs[g] = [os.path.join(tmp, g + "_genes.fna"), "no_protein"]
         bindir = os.path.join(tmp, "bin")
         os.makedirs(bindir)
