@@ -194,13 +194,17 @@ def _lineage_keys(db, res):
     combined[~ok] = -1
     uniq, first, inverse = np.unique(combined, return_index=True, return_inverse=True)
     strings = []
+    known = db.__dict__.setdefault("_assigned_bytes", {})      # (end position, selected) -> the line's second column
     for u, i in zip(uniq.tolist(), first.tolist()):
         if u < 0:
             strings.append(b"")
             continue
-        sel = int(res.selected[i])
-        selected = db.keys[sel] if sel >= 0 else -1
-        strings.append(";".join(db.lineage(res, i)[0:int(selected) + 1]).encode("utf-8"))
+        text = known.get(u)
+        if text is None:
+            sel = int(res.selected[i])
+            selected = db.keys[sel] if sel >= 0 else -1
+            text = known[u] = ";".join(db.lineage(res, i)[0:int(selected) + 1]).encode("utf-8")
+        strings.append(text)
     key = inverse.astype(np.int32)
     key[~ok] = -1
     return key, strings
