@@ -1,16 +1,17 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): the default bench, the rocprofv3 kernel trace of the same
 # command, and the two HBM-traffic counter passes (separate runs, as the MI355X guide prescribes).
-# usage: tools/collect_profiles.sh <tag>   -> gpurun_out/final_<tag>/, a directory of this run alone (it is removed
-# first: gpurun merges what every run leaves under gpurun_out/, and a summary read from a directory that an earlier
-# run also wrote into once reported a third of the real traffic); tools/summarize_profiles.py <tag> turns it into
-# profiles/<tag>_*.
+# usage: tools/collect_profiles.sh <tag>   -> gpurun_out/final_<tag>/<run id>/, a directory of this run alone, named in
+# gpurun_out/final_<tag>/run_id (gpurun MERGES what every run leaves under gpurun_out/ into the local copy, and a summary
+# read from a directory that an earlier run also wrote into once reported a third of the real traffic);
+# tools/summarize_profiles.py <tag> reads run_id and turns that one directory into profiles/<tag>_*.
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
 TAG=${1:-r3}
-O=$R/gpurun_out/final_$TAG
-rm -rf $O
+RUN=$(date +%s)_$$
+O=$R/gpurun_out/final_$TAG/$RUN      # a directory of this run alone, whatever older runs left beside it after gpurun's merge
 mkdir -p $O
+echo $RUN > $R/gpurun_out/final_$TAG/run_id
 cd /tmp && export TMPDIR=/tmp
 QUIET="--no-cpu-baseline --check 0 --host-steps 0 --onehot-lines 0 --a2m-reads 0"
 timeout -k 10 600 python3 $R/bench.py > $O/bench.json 2> $O/bench.err

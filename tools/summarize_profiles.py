@@ -15,6 +15,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(ROOT, "profiles")
 tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
 SRC = os.path.join(ROOT, "gpurun_out", "final_" + tag)      # written by ONE run of tools/collect_profiles.sh <tag>
+if os.path.exists(os.path.join(SRC, "run_id")):             # ... which names its own subdirectory there
+    SRC = os.path.join(SRC, open(os.path.join(SRC, "run_id")).read().strip())
 sys.path.insert(0, ROOT)
 from stag_amd._lib import kernel_source_sha1  # noqa: E402
 
