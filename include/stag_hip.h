@@ -154,11 +154,14 @@ int stag_onehot_text_classify(stag_db_t *db, int64_t n, const int64_t *patch_ind
 
 /* Encode + classify without the rows leaving the GPU.  bits_out (may be NULL) receives the
  * packed rows (for -S, classify.py:160-162).
- * The host form is a pipeline: the batch is cut into sub-batches of 65,536 records whose text
- * goes up on one stream while the previous sub-batch is computed on a second and the results of the one before
- * come down on a third, straight into the caller's arrays.  The copies overlap only if the caller's buffers
- * are page-locked -- stag_host_alloc gives such memory (text, offs, every output array); with pageable buffers
- * the call is still correct, the HIP runtime then stages each copy itself. */
+ * The host form is a pipeline: the batch is cut into sub-batches of about 64 MB of text (65,536
+ * to 262,144 records, the last few smaller) whose text goes up on one stream while the previous sub-batch is
+ * computed on a second and the results of the one before come down on a third, straight into the caller's arrays.
+ * The copies overlap only if the caller's buffers are page-locked -- stag_host_alloc gives such memory (text, offs,
+ * every output array); with pageable buffers the call is still correct, the HIP runtime then stages each copy itself.
+ * offs (and lead_trail below) are validated sub-batch by sub-batch, each before its upload is queued: a malformed
+ * record stops the call with STAG_E_INVALID, and the output arrays may then hold the results of the sub-batches
+ * before it. */
 int stag_classify_a2m(stag_db_t *db, const char *text, const int64_t *offs, int64_t n,
                       double min_perc_state, const stag_results_t *out, uint32_t *bits_out,
                       int32_t *n_char_out);

@@ -226,6 +226,8 @@ struct PipePool {
 } g_pipe_pool;
 }  // namespace
 
+constexpr int PIPE_SLOTS = 3;    // sub-batches of the host pipeline that are on the device at a time
+
 struct stag_db {
     int device = 0;
     int n_nodes = 0, L = 0, W = 0, nchunks = 0, max_depth = 0, n_keys = 0, n_tf = 0;
@@ -266,9 +268,10 @@ struct stag_db {
     // results (used when the caller passes NULL or host pointers)
     DevBuf<int32_t> r_path_node, r_path_len, r_lead, r_selected, r_n_aligned, r_status;
     DevBuf<double> r_path_prob, r_level_prob;
-    // host pipeline of stag_classify_a2m (pipe_setup): two slots of device text / offsets / results, a copy-in,
-    // a compute and a copy-out stream.  Slot j % 2 holds sub-batch j: its text goes up while sub-batch j - 1 is
-    // computed and the results of j - 2 come down.
+    // host pipeline of stag_classify_a2m (pipe_setup): three slots of device text / offsets / results, a copy-in,
+    // a compute and a copy-out stream.  Slot j % 3 holds sub-batch j: its text goes up while sub-batch j - 1 is
+    // computed and the results of j - 2 come down (with two slots the upload of j could not be queued before the
+    // download of j - 2 had ended, which left the link idle between uploads).
     struct Slot {
         DevBuf<uint8_t> text;
         DevBuf<int64_t> offs;
@@ -278,7 +281,7 @@ struct stag_db {
         DevBuf<uint32_t> bits;
         hipEvent_t up = nullptr, done = nullptr, down = nullptr;   // H2D finished / kernels finished / D2H finished
         bool used = false;
-    } slot[2];
+    } slot[PIPE_SLOTS];
     hipStream_t s_up = nullptr, s_run = nullptr, s_down = nullptr;
     // profiling
     bool prof = false;
@@ -1198,18 +1201,27 @@ int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *of
     if (!db || n < 0 || !out || (n > 0 && (!text || !offs || !out->status))) return fail(STAG_E_INVALID, "bad argument");
     if (n == 0) return STAG_OK;
     int rc;
-    if ((rc = check_offsets(offs, n, "offs"))) return rc;
-    if (lead_trail)
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t cols = (int64_t)lead_trail[2 * i] + lead_trail[2 * i + 1] + (offs[i + 1] - offs[i]);
-            if (lead_trail[2 * i] < 0 || lead_trail[2 * i + 1] < 0 || cols > 0x7fffffff)
-                return fail(STAG_E_INVALID, "lead_trail of record %lld: counts must be non-negative and the record shorter than 2^31 columns", (long long)i);
-        }
+    // The records are validated sub-batch by sub-batch, each right before its upload is queued (a pass over a
+    // million offsets takes as long as uploading a fifth of them: done up front it was a fifth of the call; done
+    // here it runs while the device works on the sub-batches before).  A record that fails stops the call with
+    // STAG_E_INVALID as before; the output arrays may then hold the results of the sub-batches before it.
+    auto validate = [&](int64_t b0, int64_t b1) -> int {
+        int r = check_offsets(offs + b0, b1 - b0, "offs");
+        if (r) return r;
+        if (lead_trail)
+            for (int64_t i = b0; i < b1; ++i) {
+                const int64_t cols = (int64_t)lead_trail[2 * i] + lead_trail[2 * i + 1] + (offs[i + 1] - offs[i]);
+                if (lead_trail[2 * i] < 0 || lead_trail[2 * i + 1] < 0 || cols > 0x7fffffff)
+                    return fail(STAG_E_INVALID, "lead_trail of record %lld: counts must be non-negative and the record shorter than 2^31 columns", (long long)i);
+            }
+        return STAG_OK;
+    };
+    if (offs[0] < 0 || offs[n] < offs[0]) return (rc = check_offsets(offs, n, "offs")) ? rc : fail(STAG_E_INVALID, "bad offsets");
     HIP_TRY(hipSetDevice(db->device));
     // ---- sub-batches: cut at record boundaries, at most PIPE_RECORDS records / PIPE_BYTES bytes each
     const int64_t PIPE_RECORDS = pipe_records(n, offs[n] - offs[0]), PIPE_BYTES = (int64_t)96 << 20;
     const size_t D = std::max(db->max_depth, 1), K = std::max(db->n_keys, 1);
-    if (!db->slot[1].down) {   // (the last one taken: a handle whose set-up failed half way takes the rest)
+    if (!db->slot[PIPE_SLOTS - 1].down) {   // (the last one taken: a handle whose set-up failed half way takes the rest)
         for (hipStream_t *st : {&db->s_up, &db->s_run, &db->s_down})
             if (!*st) HIP_TRY(g_pipe_pool.stream(db->device, st));
         for (auto &sl : db->slot)
@@ -1232,21 +1244,28 @@ int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *of
     } while (0)
     // the cuts first, so that everything is reserved ONCE, for the largest sub-batch, before any work is queued
     // (growing a buffer frees it, and the previous sub-batch's kernels would still be using it)
+    // The last sub-batches get smaller (each about half of what is left, down to PIPE_TAIL records): the last
+    // one's kernels and download overlap with nothing, so it should be short.  (The offsets at the cuts are looked at
+    // before they have been validated: a cut is clamped to (b0, n], and a span that makes no sense is reported by the
+    // full check.)
+    const int64_t PIPE_TAIL = std::min<int64_t>(32768, PIPE_RECORDS);
     std::vector<int64_t> cuts{0};
     int64_t max_m = 0, max_span = 0;
     while (cuts.back() < n) {
-        const int64_t b0 = cuts.back();
-        int64_t b1 = std::min(n, b0 + PIPE_RECORDS);
+        const int64_t b0 = cuts.back(), left = n - b0;
+        int64_t b1 = b0 + std::min(PIPE_RECORDS, left <= PIPE_TAIL + PIPE_TAIL / 2 ? left : std::max(left / 2, PIPE_TAIL));
         if (offs[b1] - offs[b0] > PIPE_BYTES) {   // long records: fewer of them (at least one)
             b1 = std::upper_bound(offs + b0 + 1, offs + b1 + 1, offs[b0] + PIPE_BYTES) - offs - 1;
-            b1 = std::max(b1, b0 + 1);
+            b1 = std::min(std::max(b1, b0 + 1), n);
         }
+        if (offs[b1] < offs[b0]) return (rc = check_offsets(offs, n, "offs")) ? rc : fail(STAG_E_INVALID, "bad offsets");
         cuts.push_back(b1);
         max_m = std::max(max_m, b1 - b0);
         // the 16-byte aligned stretch of the host text that holds records b0 .. b1 - 1
         max_span = std::max(max_span, (offs[b1] - (offs[b0] & ~(int64_t)15) + 15) / 16 * 16);
     }
-    for (size_t q = 0; q < std::min<size_t>(2, cuts.size() - 1); ++q) {
+    if ((rc = validate(cuts[0], cuts[1]))) return rc;      // the first sub-batch before anything is reserved or queued
+    for (size_t q = 0; q < std::min<size_t>(PIPE_SLOTS, cuts.size() - 1); ++q) {
         stag_db::Slot &sl = db->slot[q];
         if ((rc = sl.text.reserve(max_span + 16)) || (rc = sl.offs.reserve(max_m + 1)) || (rc = sl.path_node.reserve(max_m * D)) ||
             (rc = sl.path_prob.reserve(max_m * D)) || (rc = sl.path_len.reserve(max_m)) || (rc = sl.lead.reserve(max_m)) ||
@@ -1263,7 +1282,8 @@ int stag_classify_a2m_trimmed(stag_db_t *db, const char *text, const int64_t *of
     for (size_t j = 0; j + 1 < cuts.size(); ++j) {
         const int64_t b0 = cuts[j], b1 = cuts[j + 1];
         const int64_t m = b1 - b0;
-        stag_db::Slot &sl = db->slot[j & 1];
+        stag_db::Slot &sl = db->slot[j % PIPE_SLOTS];
+        if (j > 0 && (rc = validate(b0, b1))) return fin(rc);   // (while the sub-batches before are on the device)
         // the slot's previous sub-batch has left the device before its buffers are overwritten
         if (sl.used) PIPE_TRY(hipEventSynchronize(sl.down));
         // text: the 16-byte aligned stretch of the host text that holds records b0 .. b1 - 1 lands at the start of

@@ -247,7 +247,7 @@ def test_host_pipeline_sub_batches_pinned_and_pageable(monkeypatch):
     """stag_classify_a2m is a pipeline over sub-batches (text up / kernels / results down on three streams).
     Forced to 97-record sub-batches it must give what one sub-batch gives, bit for bit, with pageable and with
     page-locked (stag_host_alloc) buffers, with and without the packed rows coming back; and a malformed
-    offsets array is refused before anything is copied."""
+    offsets array is refused (its sub-batch is validated before its upload is queued)."""
     rng = np.random.default_rng(8)
     ncol = 210
     L = 5 * ncol
