@@ -13,7 +13,9 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r3"
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+PMC_ONLY = "--pmc-only" in sys.argv      # on the GPU box, between the counter passes and the bench run of collect_profiles.sh
+tag = args[0] if args else "r3"
 SRC = os.path.join(ROOT, "gpurun_out", "final_" + tag)      # written by ONE run of tools/collect_profiles.sh <tag>
 if os.path.exists(os.path.join(SRC, "run_id")):             # ... which names its own subdirectory there
     SRC = os.path.join(SRC, open(os.path.join(SRC, "run_id")).read().strip())
@@ -48,9 +50,10 @@ def counter(dirname, cname):
     return tot, {k: len(v) for k, v in disp.items()}
 
 
-shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench_final.json"))
-stats = newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
-shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
+if not PMC_ONLY:
+    shutil.copy(os.path.join(SRC, "bench.json"), os.path.join(DST, tag + "_bench_final.json"))
+    stats = newest(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(DST, tag + "_kernel_stats.csv"))
 
 fetch, nf = counter("pmc_fetch", "FETCH_SIZE")
 write, nw = counter("pmc_write", "WRITE_SIZE")
