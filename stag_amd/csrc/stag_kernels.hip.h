@@ -1310,16 +1310,29 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     // between.  The caller makes sure nobody still reads the previous slice (barrier) before, and drains the
     // DMA + barriers after.  Rows of absent lanes (seq < 0) and words past the slice keep stale data that
     // no entry of the slice refers to / whose result is never stored.
+    // (Each lane works out the address of ITS row once; a row's address then reaches the wave that stages it as two
+    // scalars: per row two v_readlane, the LDS address and the DMA -- a quarter of the instructions that computing
+    // the 64-bit address from the row's sequence id in scalar code takes.  An absent lane stands for row 0: staged
+    // like any other, never scored.)
+    const uint32_t *const my_row_words = a.bits + (size_t)max(seq, 0) * a.W;
     auto stage_rows = [&](int sA, int sB) {
         const int w0 = sA * CHUNK_WORDS;
         const int width = min(sB * CHUNK_WORDS, a.W) - w0;   // <= WCAP_CHUNKS * 16 words
+        const uint64_t at = reinterpret_cast<uint64_t>(my_row_words + w0);
+        int at_lo = (int)(uint32_t)at, at_hi = (int)(uint32_t)(at >> 32);
+        // EVERY lane needs its address in registers before the lanes past the slice's width are switched off: the
+        // readlanes below read lanes that are inactive by then, and without this the compiler moves the address
+        // arithmetic into the masked region (their registers would then hold whatever was there before)
+        asm volatile("" : "+v"(at_lo), "+v"(at_hi));
         if (lane < width) {
+            uint32_t *dst = &s_rows[wave * stride];
 #pragma unroll
             for (int rr = 0; rr < TILE / NW; ++rr) {
-                // the row's sequence id as a scalar: its address is then computed once per wave
-                const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
-                const uint32_t *src = a.bits + ((size_t)s * a.W + w0) + lane;
-                if (s >= 0 && GUARD(src, 4)) dma4(src, &s_rows[(rr * NW + wave) * stride]);
+                const uint32_t r_lo = (uint32_t)__builtin_amdgcn_readlane(at_lo, rr * NW + wave);
+                const uint32_t r_hi = (uint32_t)__builtin_amdgcn_readlane(at_hi, rr * NW + wave);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(((uint64_t)r_hi << 32) | r_lo) + lane;
+                if (GUARD(src, 4)) dma4(src, dst);
+                dst += NW * stride;
             }
         }
     };
