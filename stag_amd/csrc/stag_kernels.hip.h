@@ -1677,16 +1677,24 @@ __global__ __launch_bounds__(NW * 64, 5) void k_walk_mfma(WalkArgs a, MfmaArgs m
             const int sB = min(wB, sA + WCAP_CHUNKS);
             if (sA != wA || rd) __syncthreads();           // the previous slice's X / rows (or the C tile) have been read
             {   // row words of the slice -> LDS (LDS-DMA; lanes over words, one row per wave and step)
+                // (per-lane row addresses handed to the staging wave by v_readlane, as in k_walk_level: an absent
+                // lane stands for row 0, and every lane has its address before the lanes past the width go off)
                 const int w0 = sA * CHUNK_WORDS;
                 const int width = min(sB * CHUNK_WORDS, a.W) - w0;
+                const uint64_t at = reinterpret_cast<uint64_t>(a.bits + (size_t)max(seq, 0) * a.W + w0);
+                int at_lo = (int)(uint32_t)at, at_hi = (int)(uint32_t)(at >> 32);
+                asm volatile("" : "+v"(at_lo), "+v"(at_hi));
                 if (lane < width) {
+                    uint32_t *dst = &s_rows[wave * stride];
 #pragma unroll
                     for (int rr = 0; rr < TILE / NW; ++rr) {
-                        const int s = __builtin_amdgcn_readlane(seq, rr * NW + wave);
+                        const uint32_t a_lo = (uint32_t)__builtin_amdgcn_readlane(at_lo, rr * NW + wave);
+                        const uint32_t a_hi = (uint32_t)__builtin_amdgcn_readlane(at_hi, rr * NW + wave);
 #if STAG_ABL != 7
-                        const uint32_t *src = a.bits + ((size_t)s * a.W + w0) + lane;
-                        if (s >= 0 && GUARD(src, 4)) dma4(src, &s_rows[(rr * NW + wave) * stride]);
+                        const uint32_t *src = reinterpret_cast<const uint32_t *>(((uint64_t)a_hi << 32) | a_lo) + lane;
+                        if (GUARD(src, 4)) dma4(src, dst);
 #endif
+                        dst += NW * stride;
                     }
                 }
             }
