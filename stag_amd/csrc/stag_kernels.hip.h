@@ -1240,12 +1240,17 @@ __global__ __launch_bounds__(NW * 64, 8) void k_walk_level(WalkArgs a) {
     __shared__ __attribute__((aligned(16))) uint32_t s_mem[WALK_LDS_WORDS];
 
     const int lane = threadIdx.x & 63;
+    // The grid has a workgroup for every task there COULD be (the host does not know n_tasks): the surplus ones
+    // leave after one scalar load.  (Fetching the task record and the sequences before this test, so that all three
+    // round trips overlap, was measured: the surplus workgroups -- a third of the grid on the deep levels -- then
+    // each start two fetches they never use, and the C2 walk takes 4 % longer.)
     const int n_tasks = RDC(a.n_tasks, 0);
-    const i32x8 tk = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 2 * blockIdx.x);
-    // the task's slots of order[] sit at a fixed place: fetched together with the task record
-    // (slots past the task's count, and whole tasks past n_tasks, hold stale but allocated data)
-    SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);
     if ((int)blockIdx.x >= n_tasks) return;
+    // the task's slots of order[] sit at a fixed place: fetched together with the task record, not after it
+    // (slots past the task's count hold stale but allocated data)
+    const i32x8 tk = RDC(reinterpret_cast<const i32x8 *>(a.tasks), 2 * blockIdx.x);
+    SeqRef me = RD(a.order, (size_t)blockIdx.x * TILE + lane);
+    asm volatile("" : : "s"(tk[0]), "v"(me.seq), "v"(me.win));   // (left alone, the compiler starts the second after the first has arrived)
     const uint32_t STAG_CONST *blk_off = as_const(a.blk_off);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = tk[2], k = tk[3];
