@@ -40,6 +40,59 @@ static inline int64_t gap_run_back(const char *text, int64_t b, int64_t e) {
     return e - k;
 }
 
+#if defined(__x86_64__)
+#include <immintrin.h>
+/* The lines of an open record that need nothing but copying, as many as follow each other from *pos on: at most 64
+ * bytes before the '\n', at least one, none of them '\r' or outside ASCII, the last one not white space, no '>' in
+ * front, and all 64 bytes inside the buffer.  That is every full line `esl-reformat a2m` writes (60 columns); what it
+ * is not -- headers, the last line of a record if it is short of the buffer's end, anything odd -- stays with the
+ * byte-wise code of the caller, which this function returns to.  A line is two 32-byte loads, three compares and
+ * two stores instead of memchr + rstrip + memcpy + a scan for the high bit.  With `trim`, lines of nothing but '-'
+ * before the record's first other character are counted (*lead), not copied; the line on which that run ends is the
+ * caller's. */
+__attribute__((target("avx2,bmi"))) static void copy_plain_lines(const char *buf, int64_t len, int64_t *pos_io,
+                                                                  char *text_out, int64_t *used_io, int64_t r_text,
+                                                                  int64_t *lines_io, int64_t *lead_io, int trim) {
+    int64_t pos = *pos_io, used = *used_io, lines = *lines_io, lead = *lead_io;
+    const __m256i nl = _mm256_set1_epi8('\n'), cr = _mm256_set1_epi8('\r'), gap = _mm256_set1_epi8('-');
+    int Lp = 60;                                                /* the width `esl-reformat a2m` writes */
+    while (pos + 64 <= len && buf[pos] != '>') {
+        const __m256i a = _mm256_loadu_si256((const __m256i *)(buf + pos));
+        const __m256i b = _mm256_loadu_si256((const __m256i *)(buf + pos + 32));
+        const uint64_t m_nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, nl)) |
+                              ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, nl)) << 32);
+        if (m_nl == 0) break;                                   /* a longer line */
+        /* bytes before the '\n'.  Lines of a file mostly have one width: when this one is as wide as the last, the
+         * next line's address comes from that width (a value the processor already has) and not from this line's
+         * bytes, so that the loads of line after line are in flight together */
+        int L;
+        if (((m_nl >> Lp) & 1ull) && (m_nl & ((1ull << Lp) - 1ull)) == 0) L = Lp;
+        else Lp = L = (int)_tzcnt_u64(m_nl);
+        if (L == 0) break;                                      /* a blank line */
+        const uint64_t content = (1ull << L) - 1ull;            /* (L <= 63: the '\n' is among the 64 bytes) */
+        const uint64_t m_bad = ((uint32_t)_mm256_movemask_epi8(_mm256_or_si256(a, _mm256_cmpeq_epi8(a, cr))) |
+                                ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_or_si256(b, _mm256_cmpeq_epi8(b, cr))) << 32));
+        if (m_bad & content) break;                             /* '\r' or a byte outside ASCII */
+        if (ascii_space((unsigned char)buf[pos + L - 1])) break; /* something to strip */
+        if (trim && used == r_text) {                           /* nothing but '-' so far */
+            const uint64_t m_gap = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(a, gap)) |
+                                   ((uint64_t)(uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(b, gap)) << 32);
+            if ((m_gap & content) != content) break;            /* the run ends on this line */
+            lead += L;
+        } else {
+            /* 64 bytes are written, L of them count: the caller's text buffer has room for every byte not yet consumed */
+            _mm256_storeu_si256((__m256i *)(text_out + used), a);
+            _mm256_storeu_si256((__m256i *)(text_out + used + 32), b);
+            used += L;
+        }
+        ++lines;
+        pos += L + 1;
+    }
+    *pos_io = pos; *used_io = used; *lines_io = lines; *lead_io = lead;
+}
+#define STAG_HAVE_PLAIN_LINES 1
+#endif
+
 int64_t stag_fasta_scan(const char *buf, int64_t len, int32_t final, int32_t at_start, int64_t max_records,
                         char *text_out, int64_t text_cap, int64_t text_used_in, int64_t *offs,
                         stag_record_t *recs, int64_t *consumed, int64_t *text_used) {
@@ -72,7 +125,16 @@ int64_t stag_fasta_scan_trim(const char *buf, int64_t len, int32_t final, int32_
         }                                                                        \
     } while (0)
 
+#ifdef STAG_HAVE_PLAIN_LINES
+    const int plain_lines = __builtin_cpu_supports("avx2") && __builtin_cpu_supports("bmi");
+#endif
     while (pos < len) {
+#ifdef STAG_HAVE_PLAIN_LINES
+        if (plain_lines && open && !fb && buf[pos] != '>' && pos + 64 <= len) {
+            copy_plain_lines(buf, len, &pos, text_out, &used, r_text, &r_lines, &r_lead, lead_trail != NULL);
+            if (pos >= len) break;
+        }
+#endif
         const char *nl = (const char *)memchr(buf + pos, '\n', (size_t)(len - pos));
         if (!nl && !final) break;   /* incomplete line: wait for more bytes */
         const int64_t line_end = nl ? (int64_t)(nl - buf) : len;

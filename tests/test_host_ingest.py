@@ -401,3 +401,52 @@ def test_trimmed_records_put_back_together_are_the_records(batch_records, chunk_
     assert dropped > sum(map(len, recs)) // 3
     plain = records_of(ingest.fasta_batches(io.BytesIO(stream), batch_records=batch_records, chunk_bytes=chunk_bytes))
     assert [r[1] for r in plain] == recs
+
+
+def test_wrapped_records_with_oddities_equal_the_python_reader():
+    """The scanner copies plain lines 64 bytes at a time (copy_plain_lines, AVX2) and leaves everything else to its
+    byte-wise code: long seeded streams of wrapped records -- line widths around 64, lines ending in blanks, tabs or
+    '\\r\\n', a '\\r' or a character outside ASCII inside a line, blank lines, a '>' inside a line, lines longer than
+    64 bytes, no newline at the end -- against stag_amd.helpers.read_fasta (helpers.py:107-121), at chunk sizes
+    that cut lines anywhere; with trim, the records put back together."""
+    from stag_amd.helpers import read_fasta
+    from stag_amd.tables import ascii_stand_in
+    rng = np.random.default_rng(77)
+    odd = [b" ", b"\t", b"\r", b"\xc3\xa9", b"\xc2\xa0", b">", b"\x0b", b"  ", b"\xe2\x80\xa8"]
+    for case in range(60):
+        width = int(rng.choice([60, 61, 63, 64, 65, 80, 33, 200]))
+        parts = []
+        for i in range(int(rng.integers(1, 40))):
+            ncol = int(rng.integers(1, 700))
+            s = np.full(ncol, "-", dtype="<U1")
+            a, b = sorted(rng.integers(0, ncol + 1, size=2))
+            if i % 5:
+                s[a:b] = rng.choice(list("ACGT-Nacg."), size=b - a)
+            body = "".join(s).encode()
+            lines = [body[j:j + width] for j in range(0, len(body), width)]
+            for j in range(len(lines)):
+                r = rng.random()
+                if r < 0.04:       # something odd at the end of the line, inside it, or a blank line after it
+                    lines[j] = lines[j] + odd[int(rng.integers(0, 4))]
+                elif r < 0.08 and len(lines[j]) > 2:
+                    at = int(rng.integers(1, len(lines[j])))
+                    lines[j] = lines[j][:at] + odd[int(rng.integers(0, len(odd)))] + lines[j][at:]
+                elif r < 0.10:
+                    lines[j] = lines[j] + b"\n"
+            eol = b"\r\n" if case % 7 == 3 else b"\n"
+            parts.append(b">r%d some text\n" % i + eol.join(lines) + eol)
+        data = b"".join(parts)
+        if case % 4 == 1:
+            data = data.rstrip(b"\r\n")
+        want = [[i, ascii_stand_in(s)] for i, s in read_fasta(io.BytesIO(data), head_start=1)]
+        for chunk in (int(rng.choice([100, 257, 1000])), 4096, 1 << 20):
+            got = []
+            for ids, text, offs in ingest.fasta_batches(io.BytesIO(data), batch_records=int(rng.choice([1, 7, 1 << 16])),
+                                                        chunk_bytes=chunk):
+                got += [[sid, bytes(text[offs[i]:offs[i + 1]])] for i, sid in enumerate(ids)]
+            assert got == want, (case, chunk)
+            got = []
+            for ids, text, offs, lt in ingest.fasta_batches(io.BytesIO(data), batch_records=1 << 16, chunk_bytes=chunk, trim=True):
+                got += [[sid, b"-" * int(lt[i, 0]) + bytes(text[offs[i]:offs[i + 1]]) + b"-" * int(lt[i, 1])]
+                        for i, sid in enumerate(ids)]
+            assert got == want, (case, chunk, "trim")
