@@ -192,7 +192,9 @@ class _ShortLines:
     lineage down to the selected level) is fixed by where the sequence's path ends and which level was selected, so
     it is built once per (end position, selected level) code and kept -- all of them in one byte blob with offsets,
     which is what stag_rows_format_short indexes.  at[code] = index of the code's string (-1: not seen yet); for a
-    database whose code space is larger than DIRECT_KEYS a dict does the same."""
+    database whose code space is larger than DIRECT_KEYS a dict does the same.  Not locked: it hangs on ONE Database
+    (classify_a2m_file formats every batch with pool.first, whichever device computed it) and only the thread that
+    writes the output touches it."""
 
     def __init__(self, space):
         self.space = space
